@@ -1,0 +1,147 @@
+"""The "fixed random-init checkpoint" of BASELINE.json, regenerable from a seed.
+
+A reference checkpoint is ~320 MB (59 MiB hash table + 253 MB of ConvTranspose3d
+weights) and cannot be committed or shipped, so the state_dict is *defined* by this
+recipe: every tensor is drawn from its own torch CPU generator (seeded from the
+checkpoint seed and the tensor's key), with the distribution the reference's
+initialisers use:
+
+  * nn.Linear / nn.ConvTranspose3d: Xavier-uniform with the gain rules of ``initseq``
+    (core/utils/network_util.py:207-334), zero bias, and the 2x2x2 block replication of
+    transposed-conv kernels (:295-313);
+  * last layers of the non-rigid MLP and the pose decoder: U(-1e-5, 1e-5)
+    (mlp_offset.py:39-42, mlp_delta_body_pose.py:27-31);
+  * hash table: U(-1e-4, 1e-4) (gridencoder/grid.py:139-141); point_dist U(-1e-4, 1e-4)
+    (network.py:109-110); const_embedding N(0,1) (deconv_vol_decoder.py:15-17);
+    point_counter ones (network.py:121).
+
+Key names and shapes are exactly the reference's, so the dict
+loads with ``strict=True`` into either implementation.  ``amplify=True`` gives a
+"trained-like" variant (O(1) hash features, visible non-rigid offsets and pose
+corrections, non-uniform visibility counts) that makes parity tests sensitive to
+every stage; it is not the benchmark checkpoint.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+from .gridencoder import grid_offsets
+
+_RELU_GAIN = math.sqrt(2.0)
+_LEAKY_GAIN = math.sqrt(2.0 / (1.0 + 0.2 ** 2))
+
+
+def _gen(seed, key):
+    g = torch.Generator(device='cpu')
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) % (2 ** 63 - 1))
+    return g
+
+
+def _uniform(shape, bound, seed, key):
+    t = torch.empty(shape, dtype=torch.float32)
+    t.uniform_(-bound, bound, generator=_gen(seed, key))
+    return t
+
+
+def _xavier_linear(out_f, in_f, gain, seed, key):
+    std = gain * math.sqrt(2.0 / (in_f + out_f))
+    return _uniform((out_f, in_f), std * math.sqrt(3.0), seed, key)
+
+
+def _xavier_convT3d(in_c, out_c, gain, seed, key):
+    ksize = 4 * 4 * 4 // 2 // 2 // 2
+    std = gain * math.sqrt(2.0 / ((in_c + out_c) * ksize))
+    w = _uniform((in_c, out_c, 4, 4, 4), std * math.sqrt(3.0), seed, key)
+    base = w[:, :, 0::2, 0::2, 0::2].clone()
+    for a in (0, 1):
+        for b in (0, 1):
+            for c in (0, 1):
+                w[:, :, a::2, b::2, c::2] = base
+    return w
+
+
+def _mlp(sd, prefix, dims, gains, seed, small_last=None):
+    """dims = [in0, out0, in1, out1, ...] flattened as pairs; keys prefix.{2*i}."""
+    for i, ((fin, fout), gain) in enumerate(zip(dims, gains)):
+        kw, kb = f'{prefix}.{2 * i}.weight', f'{prefix}.{2 * i}.bias'
+        if small_last is not None and i == len(dims) - 1:
+            sd[kw] = _uniform((fout, fin), small_last, seed, kw)
+        else:
+            sd[kw] = _xavier_linear(fout, fin, gain, seed, kw)
+        sd[kb] = torch.zeros(fout)
+
+
+def make_state_dict(point_base, bound, seed=0, amplify=False, total_bones=24,
+                    cnl_width=256, cnl_depth=4, nr_width=128, nr_depth=6, nr_skips=(4,),
+                    nr_embed=36, cond_size=69, pose_width=256, pose_depth=4,
+                    embedding_size=256, volume_size=32):
+    """-> OrderedDict-compatible dict of CPU float32 tensors (offsets int32)."""
+    sd = {}
+    P = point_base.shape[0]
+    sd['point_base'] = torch.as_tensor(np.asarray(point_base)).float().clone()
+    sd['point_dist'] = _uniform((P, 1), 1e-4, seed, 'point_dist')
+    sd['point_counter'] = torch.ones(P)
+
+    # motion-weight volume decoder (network_util.py:12-50, deconv_vol_decoder.py:8-23)
+    k = 'mweight_vol_decoder.const_embedding'
+    sd[k] = torch.randn(embedding_size, generator=_gen(seed, k))
+    k = 'mweight_vol_decoder.decoder.block_mlp.0'
+    sd[k + '.weight'] = _xavier_linear(1024, embedding_size, _LEAKY_GAIN, seed, k + '.weight')
+    sd[k + '.bias'] = torch.zeros(1024)
+    inc, outc, chans = 1024, 512, []
+    for _ in range(int(np.log2(volume_size)) - 1):
+        chans.append((inc, outc))
+        if inc == outc:
+            outc = inc // 2
+        else:
+            inc = outc
+    chans.append((inc, total_bones + 1))
+    for i, (ci, co) in enumerate(chans):
+        k = f'mweight_vol_decoder.decoder.block_conv.{2 * i}'
+        gain = _LEAKY_GAIN if i < len(chans) - 1 else 1.0
+        sd[k + '.weight'] = _xavier_convT3d(ci, co, gain, seed, k + '.weight')
+        sd[k + '.bias'] = torch.zeros(co)
+
+    # non-rigid motion MLP (mlp_offset.py:7-42)
+    dims = [(nr_embed + cond_size, nr_width)]
+    for i in range(1, nr_depth):
+        dims.append((nr_width + nr_embed if i in nr_skips else nr_width, nr_width))
+    dims.append((nr_width, 3))
+    _mlp(sd, 'non_rigid_mlp.module.block_mlps', dims, [_RELU_GAIN] * nr_depth + [1.0], seed,
+         small_last=1e-2 if amplify else 1e-5)
+
+    # pose decoder (mlp_delta_body_pose.py:7-33)
+    dims = [(cond_size, pose_width)] + [(pose_width, pose_width)] * (pose_depth - 1)
+    dims.append((pose_width, 3 * (total_bones - 1)))
+    _mlp(sd, 'pose_decoder.block_mlps', dims, [_RELU_GAIN] * pose_depth + [1.0], seed,
+         small_last=2e-3 if amplify else 1e-5)
+
+    # canonical MLP (occnerf_mlp.py:31-83)
+    offsets, _ = grid_offsets(4, 16, 2.0, 16, 19, desired_resolution=2048 * bound)
+    k = 'cnl_mlp.module.encoder.embeddings'
+    sd[k] = _uniform((int(offsets[-1]), 2), 1.0 if amplify else 1e-4, seed, k)
+    sd['cnl_mlp.module.encoder.offsets'] = torch.from_numpy(offsets.copy())
+    dims = [(68, cnl_width)] + [(cnl_width, cnl_width)] * (cnl_depth - 1)
+    _mlp(sd, 'cnl_mlp.module.pts_linears', dims, [_RELU_GAIN] * cnl_depth, seed)
+    _mlp(sd, 'cnl_mlp.module.geo_linear', [(cnl_width, 65)], [1.0], seed)
+    dims = [(131, cnl_width)] + [(cnl_width, cnl_width)] * (cnl_depth - 1)
+    _mlp(sd, 'cnl_mlp.module.rgb_linears', dims, [_RELU_GAIN] * cnl_depth, seed)
+    _mlp(sd, 'cnl_mlp.module.output_linear', [(cnl_width, 3)], [1.0], seed)
+
+    if amplify:
+        g = _gen(seed, 'amplify')
+        # visibility counts: half the body "seen" often, the rest once
+        seen = torch.rand(P, generator=g) < 0.5
+        counts = 1.0 + torch.poisson(torch.full((P,), 50.0), generator=g)
+        sd['point_counter'] = torch.where(seen, counts, torch.ones(P))
+        sd['point_dist'] = _uniform((P, 1), 5e-3, seed, 'point_dist.amp')
+        sd['cnl_mlp.module.geo_linear.0.bias'][0] = 1.0      # denser field
+    return sd
+
+
+def tensor_digest(t):
+    """SHA-256 of a tensor's bytes (fixtures store digests, never the 59 MiB table)."""
+    import hashlib
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()

@@ -1,0 +1,150 @@
+"""Per-frame sub-modules of the renderer, kept as PyTorch-ROCm ops.
+
+SURVEY.md section 8(a) rows a2-a4 run once per frame on a handful of values (a 69-d
+pose vector, 24 bone transforms, one 25x32^3 volume); they stay torch modules on the
+GPU (rocBLAS / MIOpen) and produce the *inputs* of the HIP sample pipeline.  Parameter
+names and shapes are the reference's, so its checkpoints load with strict=True:
+
+  BodyPoseRefiner            core/nets/occnerf/pose_decoders/mlp_delta_body_pose.py:7-41
+  MotionBasisComputer        core/utils/network_util.py:138-200
+  MotionWeightVolumeDecoder  core/nets/occnerf/mweight_vol_decoders/deconv_vol_decoder.py:8-33
+                             (+ ConvDecoder3D, network_util.py:12-50)
+  NonRigidMotionMLP          core/nets/occnerf/non_rigid_motion_mlps/mlp_offset.py:7-62
+                             (parameter container; evaluated by the HIP kernel)
+
+Weights are left at torch's defaults here: values always come from a checkpoint
+(occnerf_amd/checkpoint.py or a reference .tar).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+SMPL_PARENT = (-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21)
+
+
+def _mlp_stack(dims, final_act=False):
+    layers = []
+    for i, (fin, fout) in enumerate(dims):
+        layers.append(nn.Linear(fin, fout))
+        if i < len(dims) - 1 or final_act:
+            layers.append(nn.ReLU())
+    return layers
+
+
+def rodrigues(rvec):
+    """Axis-angle [B,3] -> rotation [B,3,3]; theta = sqrt(1e-5 + |r|^2)
+    (network_util.py:98-124)."""
+    theta = torch.sqrt(1e-5 + torch.sum(rvec ** 2, dim=1))
+    r = rvec / theta[:, None]
+    c, s = torch.cos(theta), torch.sin(theta)
+    x, y, z = r[:, 0], r[:, 1], r[:, 2]
+    oc = 1.0 - c
+    return torch.stack((
+        x * x + (1.0 - x * x) * c, x * y * oc - z * s, x * z * oc + y * s,
+        x * y * oc + z * s, y * y + (1.0 - y * y) * c, y * z * oc - x * s,
+        x * z * oc - y * s, y * z * oc + x * s, z * z + (1.0 - z * z) * c), dim=1).view(-1, 3, 3)
+
+
+class BodyPoseRefiner(nn.Module):
+    def __init__(self, embedding_size=69, mlp_width=256, mlp_depth=4, total_bones=24, **_):
+        super().__init__()
+        self.total_bones = total_bones - 1
+        dims = [(embedding_size, mlp_width)] + [(mlp_width, mlp_width)] * (mlp_depth - 1)
+        dims.append((mlp_width, 3 * self.total_bones))
+        self.block_mlps = nn.Sequential(*_mlp_stack(dims))
+
+    def forward(self, pose_input):
+        rvec = self.block_mlps(pose_input).view(-1, 3)
+        return {'Rs': rodrigues(rvec).view(-1, self.total_bones, 3, 3)}
+
+
+class MotionBasisComputer(nn.Module):
+    """Observation-pose skeleton -> 24 (R, T) that carry observation-space points into
+    the canonical space: cnl_gtfms @ inverse(FK(dst_Rs, dst_Ts))."""
+
+    def __init__(self, total_bones=24):
+        super().__init__()
+        self.total_bones = total_bones
+
+    def forward(self, dst_Rs, dst_Ts, cnl_gtfms):
+        B, nb = dst_Rs.shape[:2]
+        local = torch.zeros(B, nb, 4, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)
+        local[:, :, :3, :3] = dst_Rs
+        local[:, :, :3, 3] = dst_Ts
+        local[:, :, 3, 3] = 1.0
+        chain = [local[:, 0]]
+        for i in range(1, nb):
+            chain.append(torch.matmul(chain[SMPL_PARENT[i]], local[:, i]))
+        dst = torch.stack(chain, dim=1).view(-1, 4, 4)
+        f = torch.matmul(cnl_gtfms.view(-1, 4, 4), torch.inverse(dst)).view(B, nb, 4, 4)
+        return f[:, :, :3, :3], f[:, :, :3, 3]
+
+
+class _ConvDecoder3D(nn.Module):
+    def __init__(self, embedding_size, volume_size, voxel_channels):
+        super().__init__()
+        self.block_mlp = nn.Sequential(nn.Linear(embedding_size, 1024), nn.LeakyReLU(0.2))
+        convs, inc, outc = [], 1024, 512
+        for _ in range(int(np.log2(volume_size)) - 1):
+            convs += [nn.ConvTranspose3d(inc, outc, 4, 2, 1), nn.LeakyReLU(0.2)]
+            if inc == outc:
+                outc = inc // 2
+            else:
+                inc = outc
+        convs.append(nn.ConvTranspose3d(inc, voxel_channels, 4, 2, 1))
+        self.block_conv = nn.Sequential(*convs)
+
+    def forward(self, embedding):
+        return self.block_conv(self.block_mlp(embedding).view(-1, 1024, 1, 1, 1))
+
+
+class MotionWeightVolumeDecoder(nn.Module):
+    def __init__(self, embedding_size=256, volume_size=32, total_bones=24):
+        super().__init__()
+        self.total_bones, self.volume_size = total_bones, volume_size
+        self.const_embedding = nn.Parameter(torch.zeros(embedding_size))
+        self.decoder = _ConvDecoder3D(embedding_size, volume_size, total_bones + 1)
+
+    def forward(self, motion_weights_priors, **_):
+        logits = self.decoder(self.const_embedding[None]) + torch.log(motion_weights_priors)
+        return F.softmax(logits, dim=1)
+
+
+class NonRigidMotionMLP(nn.Module):
+    """Parameter container with the reference's layer layout; ``forward`` is the plain
+    torch evaluation (used for autograd / as a fp32 reference of the HIP kernel)."""
+
+    def __init__(self, pos_embed_size=36, condition_code_size=69, mlp_width=128, mlp_depth=6,
+                 skips=None):
+        super().__init__()
+        self.skips = [4] if skips is None else list(skips)
+        dims = [(pos_embed_size + condition_code_size, mlp_width)]
+        self.layers_to_cat_inputs = []
+        for i in range(1, mlp_depth):
+            if i in self.skips:
+                self.layers_to_cat_inputs.append(2 * i)
+                dims.append((mlp_width + pos_embed_size, mlp_width))
+            else:
+                dims.append((mlp_width, mlp_width))
+        dims.append((mlp_width, 3))
+        self.block_mlps = nn.ModuleList(_mlp_stack(dims))
+        self.pos_embed_size, self.mlp_depth, self.mlp_width = pos_embed_size, mlp_depth, mlp_width
+
+    def forward(self, pos_embed, pos_xyz, condition_code, **_):
+        h = torch.cat([condition_code, pos_embed], dim=-1)
+        for i, layer in enumerate(self.block_mlps):
+            if i in self.layers_to_cat_inputs:
+                h = torch.cat([h, pos_embed], dim=-1)
+            h = layer(h)
+        return {'xyz': pos_xyz + h, 'offsets': h}
+
+
+def hann_window_weights(multires, iter_val, kick_in_iter, full_band_iter):
+    """Per-frequency Hann weights of the non-rigid embedding
+    (embedders/hannw_fourier.py:26-39); all ones once iter_val >= full_band_iter."""
+    t = max(float(iter_val) - float(kick_in_iter), 0.0)
+    alpha = multires * t / (float(full_band_iter) - float(kick_in_iter))
+    j = torch.arange(multires, dtype=torch.float32)
+    a = torch.tensor(alpha, dtype=torch.float32)
+    return (1.0 - torch.cos(np.pi * torch.clamp(a - j, min=0.0, max=1.0))) / 2.0

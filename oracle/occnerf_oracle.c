@@ -1,0 +1,685 @@
+/*
+ * occnerf_oracle.c -- CPU restatement of OccNeRF's per-ray rendering hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under occnerf_amd/ (the product) may import,
+ * link or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and only as the checker / the timed CPU baseline.
+ *
+ * Every function restates one row of SURVEY.md section 8(a) and cites the reference
+ * lines it follows (paths relative to the reference checkout).  Arithmetic is fp32
+ * unless the reference computes in fp64 (the float64 vertex normals make the
+ * neighbour-geometry prelude fp64, see oc_sample_geometry).  Built with
+ * -ffp-contract=off: every fused multiply-add below is an explicit fmaf(), so the
+ * HIP kernels can reproduce the integer-valued results (hash indices, kNN indices)
+ * bit for bit.
+ *
+ * Pinning status (DESIGN.md "Oracle"):
+ *   - pinned by running the reference's own Python (core/nets/occnerf/network.py,
+ *     canonical_mlps/occnerf_mlp.py, ...) in the build container and committing its
+ *     inputs/outputs under tests/golden/ (oracle/ref_harness/make_golden.py);
+ *   - PARITY UNPINNED for the two third-party kernels the reference only ships or
+ *     calls as GPU code: the torch-ngp grid encoder (gridencoder/src/gridencoder.cu,
+ *     CUDA only, cannot execute here) and pykeops' Kmin_argKmin (pykeops is not
+ *     vendored; requirements.txt:11, unpinned).  Both are restated from source /
+ *     published semantics and cross-checked against an independent numpy/float64
+ *     implementation in the harness.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define OC_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* a14: multi-resolution hash-grid encoding                                   */
+/* gridencoder/src/gridencoder.cu:50-84 (index), :87-245 (forward)            */
+/* ------------------------------------------------------------------------- */
+
+static const uint32_t OC_PRIMES[7] = {1u, 2654435761u, 805459861u, 3674653429u,
+                                      2097192037u, 1434869437u, 2165219737u};
+
+/* gridencoder.cu:66-84.  All arithmetic is uint32 with wrap-around. */
+static inline uint32_t oc_grid_index(uint32_t D, uint32_t C, uint32_t gridtype,
+                                     int align_corners, uint32_t hashmap_size,
+                                     uint32_t resolution, const uint32_t *pos_grid) {
+    uint32_t stride = 1, index = 0;
+    for (uint32_t d = 0; d < D && stride <= hashmap_size; d++) {
+        index += pos_grid[d] * stride;
+        stride *= align_corners ? resolution : (resolution + 1);
+    }
+    if (gridtype == 0 && stride > hashmap_size) {
+        uint32_t h = 0;                                   /* fast_hash, :50-63 */
+        for (uint32_t d = 0; d < D; d++) h ^= pos_grid[d] * OC_PRIMES[d];
+        index = h;
+    }
+    return (index % hashmap_size) * C;
+}
+
+/* Per-level constants, gridencoder.cu:137-139.  The CUDA source writes
+ * exp2f(level * S) * H - 1.0f, which nvcc contracts to one fma; the same
+ * contraction is spelled out here and the HIP build receives this table from the
+ * host, so device exp2f accuracy never enters the result. */
+OC_EXPORT void oc_grid_level_params(uint32_t L, float S, uint32_t H, float *scale,
+                                    uint32_t *resolution) {
+    for (uint32_t l = 0; l < L; l++) {
+        scale[l] = fmaf(exp2f((float)l * S), (float)H, -1.0f);
+        resolution[l] = (uint32_t)ceilf(scale[l]) + 1;
+    }
+}
+
+/* One sample, all levels.  out[level * out_stride + ch]; dyl[level * D * C + ...]. */
+static inline void oc_grid_encode_one(const float *x, const float *embeddings,
+                                      const int32_t *offsets, const float *scale_l,
+                                      const uint32_t *res_l, uint32_t D, uint32_t C, uint32_t L,
+                                      uint32_t gridtype, int align_corners, uint32_t interp,
+                                      float *outp, size_t out_stride, float *dy) {
+    int oob = 0;
+    for (uint32_t d = 0; d < D; d++)
+        if (x[d] < 0 || x[d] > 1) oob = 1;                   /* :110-116 */
+    for (uint32_t level = 0; level < L; level++) {
+        float *out = outp + (size_t)level * out_stride;
+        float *dyl = dy ? dy + (size_t)level * D * C : NULL;
+        if (oob) {                                            /* :118-135 */
+            for (uint32_t ch = 0; ch < C; ch++) out[ch] = 0;
+            if (dyl) for (uint32_t i = 0; i < D * C; i++) dyl[i] = 0;
+            continue;
+        }
+        const float *grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        const float scale = scale_l[level];
+        const uint32_t resolution = res_l[level];
+        float pos[8], pos_deriv[8];
+        uint32_t pos_grid[8];
+        for (uint32_t d = 0; d < D; d++) {                    /* :146-159 */
+            pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+            pos_grid[d] = (uint32_t)floorf(pos[d]);
+            pos[d] -= (float)pos_grid[d];
+            if (interp == 1) {
+                pos_deriv[d] = 6 * pos[d] * (1.0f - pos[d]);
+                pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+            } else {
+                pos_deriv[d] = 1.0f;
+            }
+        }
+        float results[8] = {0};
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {      /* :166-191 */
+            float w = 1;
+            uint32_t pl[8];
+            for (uint32_t d = 0; d < D; d++) {
+                if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+            }
+            const uint32_t index = oc_grid_index(D, C, gridtype, align_corners, hashmap_size,
+                                                 resolution, pl);
+            for (uint32_t ch = 0; ch < C; ch++)
+                results[ch] = fmaf(w, grid[index + ch], results[ch]);
+        }
+        for (uint32_t ch = 0; ch < C; ch++) out[ch] = results[ch];
+        if (dyl) {                                            /* :201-244 */
+            for (uint32_t gd = 0; gd < D; gd++) {
+                float rg[8] = {0};
+                for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                    float w = scale;
+                    uint32_t pl[8];
+                    for (uint32_t nd = 0; nd < D - 1; nd++) {
+                        const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                        if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                        else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+                    }
+                    pl[gd] = pos_grid[gd];
+                    const uint32_t il = oc_grid_index(D, C, gridtype, align_corners,
+                                                      hashmap_size, resolution, pl);
+                    pl[gd] = pos_grid[gd] + 1;
+                    const uint32_t ir = oc_grid_index(D, C, gridtype, align_corners,
+                                                      hashmap_size, resolution, pl);
+                    for (uint32_t ch = 0; ch < C; ch++)
+                        rg[ch] = fmaf(w * (grid[ir + ch] - grid[il + ch]), pos_deriv[gd], rg[ch]);
+                }
+                for (uint32_t ch = 0; ch < C; ch++) dyl[gd * C + ch] = rg[ch];
+            }
+        }
+    }
+}
+
+/* inputs[B,D] in [0,1]; embeddings[sO,C]; offsets[L+1]; outputs[L,B,C] (level-major,
+ * gridencoder.cu:108); dy_dx[B,L,D,C] or NULL.  interp 0 linear / 1 smoothstep. */
+OC_EXPORT void oc_grid_encode_forward(const float *inputs, const float *embeddings,
+                                      const int32_t *offsets, float *outputs, uint32_t B,
+                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                      float *dy_dx, uint32_t gridtype, int align_corners,
+                                      uint32_t interp) {
+    float scale_l[32];
+    uint32_t res_l[32];
+    oc_grid_level_params(L, S, H, scale_l, res_l);
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++)
+        oc_grid_encode_one(inputs + (size_t)b * D, embeddings, offsets, scale_l, res_l, D, C, L,
+                           gridtype, align_corners, interp, outputs + (size_t)b * C,
+                           (size_t)B * C, dy_dx ? dy_dx + (size_t)b * L * D * C : NULL);
+}
+
+/* a19: gridencoder.cu:248-340 (scatter into grad_embeddings, zeros-initialised by the
+ * caller) and :343-369 (input gradient from the saved dy_dx).  The CUDA kernel scatters
+ * with atomics in nondeterministic order; this restatement accumulates in (b, level,
+ * corner) order, so comparisons against it carry an fp32 reordering tolerance. */
+OC_EXPORT void oc_grid_encode_backward(const float *grad, const float *inputs,
+                                       const int32_t *offsets, float *grad_embeddings,
+                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                       uint32_t H, const float *dy_dx, float *grad_inputs,
+                                       uint32_t gridtype, int align_corners, uint32_t interp) {
+    float scale_l[32];
+    uint32_t res_l[32];
+    oc_grid_level_params(L, S, H, scale_l, res_l);
+    for (uint32_t level = 0; level < L; level++) {
+        float *gg = grad_embeddings + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *x = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[8];
+            uint32_t pos_grid[8];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(x[d], scale_l[level], align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+            }
+            const float *g = grad + ((size_t)level * B + b) * C;
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+                uint32_t pl[8];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = oc_grid_index(D, C, gridtype, align_corners,
+                                                     hashmap_size, res_l[level], pl);
+                for (uint32_t ch = 0; ch < C; ch++) gg[index + ch] += w * g[ch];
+            }
+        }
+    }
+    if (dy_dx && grad_inputs) {
+        for (uint32_t b = 0; b < B; b++)
+            for (uint32_t d = 0; d < D; d++) {
+                float r = 0;
+                for (uint32_t l = 0; l < L; l++)
+                    for (uint32_t ch = 0; ch < C; ch++)
+                        r += grad[((size_t)l * B + b) * C + ch] *
+                             dy_dx[(((size_t)b * L + l) * D + d) * C + ch];
+                grad_inputs[(size_t)b * D + d] = r;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a6: samples along rays.  network.py:405-432,456                            */
+/* rays[n,8] = (o, d, near, far); t_vals[S] = torch.linspace(0,1,S) (passed   */
+/* in so its rounding is torch's own); t_rand[n,S] or NULL (perturb == 0).    */
+/* ------------------------------------------------------------------------- */
+OC_EXPORT void oc_sample_rays(const float *rays, const float *t_vals, const float *t_rand,
+                              int64_t n, int S, float *z_vals, float *pts) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; r++) {
+        const float *ry = rays + r * 8;
+        const float near = ry[6], far = ry[7];
+        float *z = z_vals + r * S;
+        for (int s = 0; s < S; s++)                           /* :416-420 */
+            z[s] = near * (1.0f - t_vals[s]) + far * t_vals[s];
+        if (t_rand) {                                         /* :423-432 */
+            float *tmp = (float *)malloc(sizeof(float) * S);
+            for (int s = 0; s < S; s++) {
+                const float lower = s == 0 ? z[0] : 0.5f * (z[s] + z[s - 1]);
+                const float upper = s == S - 1 ? z[S - 1] : 0.5f * (z[s + 1] + z[s]);
+                tmp[s] = lower + (upper - lower) * t_rand[r * S + s];
+            }
+            memcpy(z, tmp, sizeof(float) * S);
+            free(tmp);
+        }
+        for (int s = 0; s < S; s++)                           /* :456 */
+            for (int c = 0; c < 3; c++)
+                pts[(r * S + s) * 3 + c] = ry[c] + ry[3 + c] * z[s];
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a7: backward warp through the motion-weight volume.  network.py:351-402    */
+/* F.grid_sample(trilinear, zeros padding, align_corners=True) restated from  */
+/* ATen's grid_sampler_3d: ((g+1)/2)*(size-1), floor, 8 corners added in the  */
+/* order tnw,tne,tsw,tse,bnw,bne,bsw,bse, each only when inside the volume.   */
+/* Rs[nb,3,3], Ts[nb,3], vol[nb(+1),G,G,G] (background channel ignored).      */
+/* ------------------------------------------------------------------------- */
+static inline float oc_trilinear(const float *vol, int G, float gx, float gy, float gz) {
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(G - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(G - 1);
+    const float iz = ((gz + 1.0f) / 2.0f) * (float)(G - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    /* outside by more than one voxel: every corner is out of bounds */
+    if (!(fx >= -1.0f && fx <= (float)G && fy >= -1.0f && fy <= (float)G && fz >= -1.0f &&
+          fz <= (float)G))
+        return 0.0f;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    const float wx1 = ix - (float)x0, wx0 = (float)x1 - ix;
+    const float wy1 = iy - (float)y0, wy0 = (float)y1 - iy;
+    const float wz1 = iz - (float)z0, wz0 = (float)z1 - iz;
+#define OC_IN(z, y, x) ((x) >= 0 && (x) < G && (y) >= 0 && (y) < G && (z) >= 0 && (z) < G)
+#define OC_AT(z, y, x) vol[((size_t)(z) * G + (y)) * G + (x)]
+    float out = 0.0f;
+    if (OC_IN(z0, y0, x0)) out += OC_AT(z0, y0, x0) * (wx0 * wy0 * wz0);
+    if (OC_IN(z0, y0, x1)) out += OC_AT(z0, y0, x1) * (wx1 * wy0 * wz0);
+    if (OC_IN(z0, y1, x0)) out += OC_AT(z0, y1, x0) * (wx0 * wy1 * wz0);
+    if (OC_IN(z0, y1, x1)) out += OC_AT(z0, y1, x1) * (wx1 * wy1 * wz0);
+    if (OC_IN(z1, y0, x0)) out += OC_AT(z1, y0, x0) * (wx0 * wy0 * wz1);
+    if (OC_IN(z1, y0, x1)) out += OC_AT(z1, y0, x1) * (wx1 * wy0 * wz1);
+    if (OC_IN(z1, y1, x0)) out += OC_AT(z1, y1, x0) * (wx0 * wy1 * wz1);
+    if (OC_IN(z1, y1, x1)) out += OC_AT(z1, y1, x1) * (wx1 * wy1 * wz1);
+#undef OC_IN
+#undef OC_AT
+    return out;
+}
+
+OC_EXPORT void oc_motion_field(const float *pts, int64_t N, const float *Rs, const float *Ts,
+                               const float *vol, int nb, int G, const float *bbox_min,
+                               const float *bbox_scale, float *x_skel, float *mask) {
+    const size_t vsz = (size_t)G * G * G;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++) {
+        const float *p = pts + i * 3;
+        float wsum = 0.0f, acc[3] = {0, 0, 0};
+        for (int b = 0; b < nb; b++) {
+            const float *R = Rs + b * 9, *T = Ts + b * 3;
+            float pos[3], g[3];
+            for (int c = 0; c < 3; c++) {                     /* :367,:382 */
+                pos[c] = fmaf(R[c * 3 + 2], p[2], fmaf(R[c * 3 + 1], p[1], R[c * 3] * p[0])) + T[c];
+                g[c] = (pos[c] - bbox_min[c]) * bbox_scale[c] - 1.0f;   /* :368-369 */
+            }
+            const float w = oc_trilinear(vol + b * vsz, G, g[0], g[1], g[2]);
+            wsum += w;                                        /* :377-378 */
+            for (int c = 0; c < 3; c++) acc[c] += w * pos[c]; /* :383-388 */
+        }
+        const float den = wsum < 0.0001f ? 0.0001f : wsum;    /* :388 clamp(min=1e-4) */
+        for (int c = 0; c < 3; c++) x_skel[i * 3 + c] = acc[c] / den;
+        mask[i] = wsum;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* dense layer helper: y[out] = act(W[out,in] x + b), fp32, k-ordered fma chain */
+/* ------------------------------------------------------------------------- */
+static void oc_linear(const float *W, const float *b, const float *x, int in, int out,
+                      float *y, int relu) {
+    for (int o = 0; o < out; o++) {
+        float acc = b[o];
+        const float *w = W + (size_t)o * in;
+        for (int k = 0; k < in; k++) acc = fmaf(w[k], x[k], acc);
+        y[o] = (relu && acc < 0.0f) ? 0.0f : acc;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a9: non-rigid offset.  embedders/hannw_fourier.py:9-63,                    */
+/* non_rigid_motion_mlps/mlp_offset.py:45-62.                                 */
+/* W/b: 7 layers in torch layout: [128,105] [128,128]x3 [128,164] [128,128]   */
+/* [3,128]; skip concatenates the embedding before layer index 4.             */
+/* hann[nfreq] are the window weights (all 1 at eval).                        */
+/* ------------------------------------------------------------------------- */
+OC_EXPORT void oc_nonrigid(const float *xyz, int64_t N, const float *cond, int ncond,
+                           const float *hann, int nfreq, const float *const *W,
+                           const float *const *Bv, int width, int depth, int skip_layer,
+                           float *xyz_out) {
+    const int nemb = nfreq * 6;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++) {
+        float emb[64], h0[512], h1[512];
+        const float *p = xyz + i * 3;
+        for (int f = 0; f < nfreq; f++) {
+            const float freq = (float)(1 << f);
+            for (int c = 0; c < 3; c++) {
+                emb[f * 6 + c] = hann[f] * sinf(p[c] * freq);
+                emb[f * 6 + 3 + c] = hann[f] * cosf(p[c] * freq);
+            }
+        }
+        memcpy(h0, cond, sizeof(float) * ncond);
+        memcpy(h0 + ncond, emb, sizeof(float) * nemb);
+        int in = ncond + nemb;
+        float *cur = h0, *nxt = h1;
+        for (int l = 0; l < depth; l++) {
+            if (l == skip_layer) { memcpy(cur + in, emb, sizeof(float) * nemb); in += nemb; }
+            oc_linear(W[l], Bv[l], cur, in, width, nxt, 1);
+            float *t = cur; cur = nxt; nxt = t;
+            in = width;
+        }
+        float off[3];
+        oc_linear(W[depth], Bv[depth], cur, in, 3, off, 0);
+        for (int c = 0; c < 3; c++) xyz_out[i * 3 + c] = p[c] + off[c];
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a10: exact k nearest neighbours, the arithmetic pykeops performs for       */
+/* knn.py:46-83: dij = (xi - xj).norm2() = sqrt(sum((xi-xj)^2)) in fp32, then  */
+/* Kmin_argKmin(k): the k smallest per query, ascending, candidates scanned in */
+/* ascending j and inserted on strict '<' (a tie keeps the lower index first). */
+/* pykeops is a third-party dependency absent from the reference tree          */
+/* (requirements.txt:11, unpinned) -> PARITY UNPINNED beyond these semantics.  */
+/* The squared distance is the fma chain nvcc emits for 'acc += d*d'.          */
+/* ------------------------------------------------------------------------- */
+static inline float oc_dist(const float *q, const float *s) {
+    const float dx = q[0] - s[0], dy = q[1] - s[1], dz = q[2] - s[2];
+    return sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+}
+
+OC_EXPORT void oc_knn(const float *q, int64_t nq, const float *s, int ns, int k,
+                      int32_t *idx_out, float *dist_out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nq; i++) {
+        float bd[64];
+        int32_t bi[64];
+        for (int j = 0; j < k; j++) { bd[j] = INFINITY; bi[j] = 0; }
+        for (int j = 0; j < ns; j++) {
+            const float d = oc_dist(q + i * 3, s + (size_t)j * 3);
+            if (d < bd[k - 1]) {
+                int p = k - 1;
+                while (p > 0 && d < bd[p - 1]) { bd[p] = bd[p - 1]; bi[p] = bi[p - 1]; p--; }
+                bd[p] = d; bi[p] = j;
+            }
+        }
+        for (int j = 0; j < k; j++) {
+            idx_out[i * k + j] = bi[j];
+            if (dist_out) dist_out[i * k + j] = bd[j];
+        }
+    }
+}
+
+/* network.py:235-255: the block-diagonal KeOps reduction over the 4 point scales is 4
+ * independent kNNs; indices of the coarse scales are mapped back to base-point indices
+ * through fps_index (:254-255).  base[P,3]; fps[l] = indices of scale l+1; out[N,4,k]. */
+OC_EXPORT void oc_msknn(const float *xyz, int64_t N, const float *base, int P,
+                        const int32_t *const *fps, const int32_t *nfps, int nscale, int k,
+                        int32_t *knn_idxs) {
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)N * k);
+    for (int l = 0; l < nscale; l++) {
+        const float *set = base;
+        int ns = P;
+        float *sub = NULL;
+        if (l > 0) {
+            ns = nfps[l - 1];
+            sub = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
+            for (int j = 0; j < ns; j++) memcpy(sub + j * 3, base + (size_t)fps[l - 1][j] * 3, 12);
+            set = sub;
+        }
+        oc_knn(xyz, N, set, ns, k, tmp, NULL);
+        for (int64_t i = 0; i < N; i++)
+            for (int j = 0; j < k; j++) {
+                const int32_t v = tmp[i * k + j];
+                knn_idxs[(i * nscale + l) * k + j] = l == 0 ? v : fps[l - 1][v];
+            }
+        free(sub);
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------- */
+/* cosine similarity exactly as torch 2.x evaluates F.cosine_similarity(x1, x2) when  */
+/* x1 is float32 and x2 float64 (the trimesh normals): each operand is normalised in  */
+/* ITS OWN dtype, x1 / max(|x1|, eps) in fp32 and x2 / max(|x2|, eps) in fp64, and     */
+/* only the products are promoted to fp64 (measured against torch 2.10 in the build    */
+/* container: bit-identical).  eps = 1e-8.                                             */
+/* ------------------------------------------------------------------------- */
+/* torch's fp32 2-norm of a 3-vector is sqrt(fma(z,z,fma(y,y,x*x))) (ATen's reduction is
+ * built with contraction on; checked bit-exact against torch 2.10 CPU). */
+static inline float oc_norm3(const float *a) {
+    return sqrtf(fmaf(a[2], a[2], fmaf(a[1], a[1], a[0] * a[0])));
+}
+
+static inline double oc_cos3(const float *a, const double *b) {
+    float na = oc_norm3(a);
+    double nb = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    if (na < 1e-8f) na = 1e-8f;
+    if (nb < 1e-8) nb = 1e-8;
+    return (double)(a[0] / na) * (b[0] / nb) + (double)(a[1] / na) * (b[1] / nb) +
+           (double)(a[2] / na) * (b[2] / nb);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a11: per-point signed-distance block, network.py:263-284 (chunk-invariant). */
+/* point_cloud = point_base + point_dist; normals are float64 (trimesh).       */
+/* Outputs knn_base[P,3] in fp64 (as the reference's type promotion leaves it) */
+/* and dist[P] fp32.                                                           */
+/* ------------------------------------------------------------------------- */
+OC_EXPORT void oc_point_sdf(const float *point_cloud, const float *point_base,
+                            const double *normals, int P, double *knn_base, float *dist) {
+    int32_t *kidx = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)P);
+    oc_knn(point_cloud, P, point_base, P, 3, kidx, NULL);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        double num[3] = {0, 0, 0}, den = 0;
+        float dsum = 0;
+        int neg = 0;
+        for (int j = 0; j < 3; j++) {
+            const int32_t n = kidx[i * 3 + j];
+            float dirf[3];
+            for (int c = 0; c < 3; c++) dirf[c] = point_cloud[i * 3 + c] - point_base[n * 3 + c];
+            const double att = fabs(oc_cos3(dirf, normals + (size_t)n * 3));  /* :275 */
+            for (int c = 0; c < 3; c++) num[c] += att * (double)point_base[n * 3 + c];
+            den += att;
+            const float nf[3] = {(float)normals[n * 3], (float)normals[n * 3 + 1],
+                                 (float)normals[n * 3 + 2]};
+            const float dot = dirf[0] * nf[0] + dirf[1] * nf[1] + dirf[2] * nf[2];  /* :278 */
+            neg += dot < 0;
+            dsum += oc_norm3(dirf);
+        }
+        for (int c = 0; c < 3; c++) knn_base[i * 3 + c] = num[c] / den;       /* :276 */
+        float d = dsum / 3.0f;                                                /* :281 */
+        if (neg > 1) d = -d;                                  /* sum > 1.5, :279,:282 */
+        dist[i] = d;
+    }
+    free(kidx);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a13: neighbour geometry for one sample.  occnerf_mlp.py:144-167.            */
+/* nbr = point_base[knn_idxs[:,0]] (10 finest neighbours), normals float64.    */
+/* enc_in[4] = (q, normed_dist); dist_out = signed mean distance.              */
+/* ------------------------------------------------------------------------- */
+static void oc_sample_geometry(const float *xyz, const int32_t *nbr_idx, int k,
+                               const float *point_base, const double *normals, float bound,
+                               float two_bound, float *enc_in, float *dist_out) {
+    float dirf[16][3];
+    int neg = 0;
+    float dsum = 0;
+    for (int j = 0; j < k; j++) {
+        const int32_t n = nbr_idx[j];
+        double dot = 0;
+        for (int c = 0; c < 3; c++) {
+            dirf[j][c] = xyz[c] - point_base[n * 3 + c];                      /* :147 */
+            dot += (double)dirf[j][c] * normals[(size_t)n * 3 + c];           /* :152 */
+        }
+        neg += dot < 0;
+        dsum += oc_norm3(dirf[j]);
+    }
+    float dist = dsum / (float)k;                                             /* :155 */
+    if ((double)neg > k * 0.5) dist = -dist;                                  /* :153,:156 */
+    float nd = (dist + 0.2f) / 0.5f;                                          /* :157 */
+    nd = nd < 0.0f ? 0.0f : (nd > 1.0f ? 1.0f : nd);
+    double num[3] = {0, 0, 0}, den = 0;
+    for (int j = 0; j < 3; j++) {                                             /* :164-166 */
+        const int32_t n = nbr_idx[j];
+        const double att = fabs(oc_cos3(dirf[j], normals + (size_t)n * 3));
+        for (int c = 0; c < 3; c++) {
+            const float pn = (point_base[n * 3 + c] + bound) / two_bound;    /* :164 */
+            num[c] += att * (double)pn;
+        }
+        den += att;
+    }
+    for (int c = 0; c < 3; c++) enc_in[c] = (float)(num[c] / den);
+    enc_in[3] = nd;
+    *dist_out = dist;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a15 (first half): per-point feature table, occnerf_mlp.py:171-175.          */
+/* table[P,35] = [encode(knn_base01, sdf01)(32), learnable_xyz(3)].            */
+/* ------------------------------------------------------------------------- */
+OC_EXPORT void oc_point_table(const double *knn_base, const float *point_sdf,
+                              const float *learnable, int P, float bound, float two_bound,
+                              const float *embeddings, const int32_t *offsets, uint32_t L,
+                              uint32_t C, float S, uint32_t H, float *table) {
+    const int F = (int)(L * C);
+    float *in = (float *)malloc(sizeof(float) * 4 * (size_t)P);
+    float *enc = (float *)malloc(sizeof(float) * (size_t)F * P);
+    for (int i = 0; i < P; i++) {
+        for (int c = 0; c < 3; c++)                                           /* :171 */
+            in[i * 4 + c] = (float)((knn_base[i * 3 + c] + (double)bound) / (double)two_bound);
+        float s = (point_sdf[i] + 0.2f) / 0.8f;                               /* :172 */
+        in[i * 4 + 3] = s < 0.0f ? 0.0f : (s > 1.0f ? 1.0f : s);
+    }
+    oc_grid_encode_forward(in, embeddings, offsets, enc, (uint32_t)P, 4, C, L, S, H, NULL, 0, 0, 0);
+    for (int i = 0; i < P; i++) {
+        for (uint32_t l = 0; l < L; l++)
+            for (uint32_t c = 0; c < C; c++)                                  /* grid.py:58 */
+                table[(size_t)i * (F + 3) + l * C + c] = enc[((size_t)l * P + i) * C + c];
+        for (int c = 0; c < 3; c++) table[(size_t)i * (F + 3) + F + c] = learnable[i * 3 + c];
+    }
+    free(in);
+    free(enc);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a13 + a14 + a15 + a16: CanonicalMLP.forward for N samples,                  */
+/* occnerf_mlp.py:142-199 (+ simple_agg :86-126).                              */
+/* knn_idxs[N,nscale,k] base-point indices; counter[P] visibility counts;      */
+/* Wg/Bg: geometry trunk, depth hidden layers then geo_linear [65,width];      */
+/* Wc/Bc: colour trunk, depth hidden layers then output_linear [3,width].      */
+/* raw[N,5] = (rgb logits 3, sigma, signed dist).  mlp_in[N,68] optional dump. */
+/* ------------------------------------------------------------------------- */
+OC_EXPORT void oc_canonical_mlp(const float *xyz, int64_t N, const int32_t *knn_idxs,
+                                int nscale, int k, const float *point_base,
+                                const double *normals, const float *counter,
+                                const float *table, float bound, float two_bound,
+                                const float *embeddings, const int32_t *offsets, uint32_t L,
+                                uint32_t C, float S, uint32_t H, const float *const *Wg,
+                                const float *const *Bg, const float *const *Wc,
+                                const float *const *Bc, int depth, int width, float *raw,
+                                float *mlp_in) {
+    const int F = (int)(L * C);        /* 32 */
+    const int TF = F + 3;              /* 35 */
+    const int nk = nscale * k;         /* 40 */
+    const int in_g = TF + 1 + F;       /* 68 */
+    const int in_c = 64 + TF + F;      /* 131 */
+    float scale_l[32];
+    uint32_t res_l[32];
+    oc_grid_level_params(L, S, H, scale_l, res_l);
+#pragma omp parallel
+    {
+        float *h0 = (float *)malloc(sizeof(float) * (size_t)(width + in_c + 8));
+        float *h1 = (float *)malloc(sizeof(float) * (size_t)(width + in_c + 8));
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < N; i++) {
+            const int32_t *id = knn_idxs + i * nk;
+            float enc_in[4], dist, enc[64];
+            oc_sample_geometry(xyz + i * 3, id, k, point_base, normals, bound, two_bound, enc_in,
+                               &dist);
+            oc_grid_encode_one(enc_in, embeddings, offsets, scale_l, res_l, 4, C, L, 0, 0, 0, enc,
+                               C, NULL);                      /* [L*C], grid.py:58 */
+            /* simple_agg, occnerf_mlp.py:110-125 */
+            float att[64], amin = INFINITY, amax = -INFINITY;
+            for (int j = 0; j < nk; j++) { att[j] = counter[id[j]]; amin = fminf(amin, att[j]); }
+            for (int j = 0; j < nk; j++) { att[j] += 1.0f - amin; amax = fmaxf(amax, att[j]); }
+            float mean = 0;
+            for (int j = 0; j < nk; j++) { att[j] /= amax; mean += att[j]; }
+            mean /= (float)nk;
+            float var = 0;
+            for (int j = 0; j < nk; j++) var += (att[j] - mean) * (att[j] - mean);
+            var /= (float)(nk - 1);                           /* torch.var: unbiased */
+            float smax = -INFINITY, ssum = 0;
+            for (int j = 0; j < nk; j++) smax = fmaxf(smax, att[j]);
+            for (int j = 0; j < nk; j++) { att[j] = expf(att[j] - smax); ssum += att[j]; }
+            float agg[64];
+            for (int f = 0; f < TF; f++) agg[f] = 0;
+            for (int j = 0; j < nk; j++) {
+                const float a = att[j] / ssum;
+                const float *row = table + (size_t)id[j] * TF;
+                for (int f = 0; f < TF; f++) agg[f] += a * row[f];
+            }
+            /* geometry trunk, :181-189 */
+            memcpy(h0, agg, sizeof(float) * TF);
+            h0[TF] = var;
+            memcpy(h0 + TF + 1, enc, sizeof(float) * F);
+            if (mlp_in) memcpy(mlp_in + i * in_g, h0, sizeof(float) * in_g);
+            float *cur = h0, *nxt = h1;
+            int in = in_g;
+            for (int l = 0; l < depth; l++) {
+                oc_linear(Wg[l], Bg[l], cur, in, width, nxt, 1);
+                float *t = cur; cur = nxt; nxt = t;
+                in = width;
+            }
+            float geo[80];
+            oc_linear(Wg[depth], Bg[depth], cur, in, 65, geo, 0);
+            const float sigma = geo[0];
+            /* colour trunk, :191-196 */
+            memcpy(h0, geo + 1, sizeof(float) * 64);
+            memcpy(h0 + 64, agg, sizeof(float) * TF);
+            memcpy(h0 + 64 + TF, enc, sizeof(float) * F);
+            cur = h0; nxt = h1; in = in_c;
+            for (int l = 0; l < depth; l++) {
+                oc_linear(Wc[l], Bc[l], cur, in, width, nxt, 1);
+                float *t = cur; cur = nxt; nxt = t;
+                in = width;
+            }
+            float rgb[3];
+            oc_linear(Wc[depth], Bc[depth], cur, in, 3, rgb, 0);
+            float *o = raw + i * 5;                           /* :199 */
+            o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sigma; o[4] = dist;
+        }
+        free(h0);
+        free(h1);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a17: alpha compositing.  network.py:320-348.                                */
+/* raw[n,S,5], mask[n,S], z_vals[n,S], rays_d[n,3] (stride 8 floats from the   */
+/* packed ray record allowed via d_stride), bg[3] in 0..255.                   */
+/* ------------------------------------------------------------------------- */
+static inline float oc_softplus(float x) {       /* F.softplus beta=1, threshold=20 */
+    return x > 20.0f ? x : log1pf(expf(x));
+}
+static inline float oc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+OC_EXPORT void oc_raw2outputs(const float *raw, const float *mask, const float *z_vals,
+                              const float *rays_d, int d_stride, const float *bg, int64_t n,
+                              int S, float *rgb_map, float *acc_map, float *depth_map,
+                              float *weights_out, int32_t *term_point) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; r++) {
+        const float *d = rays_d + r * d_stride;
+        const float dn = oc_norm3(d);
+        float T = 1.0f, acc = 0, depth = 0, c[3] = {0, 0, 0}, amax = -INFINITY;
+        int32_t arg = 0;
+        for (int s = 0; s < S; s++) {
+            const float *rw = raw + (r * S + s) * 5;
+            float dist = s + 1 < S ? z_vals[r * S + s + 1] - z_vals[r * S + s] : 1e10f;
+            dist *= dn;                                                       /* :325-328 */
+            float alpha = 1.0f - expf(-oc_softplus(rw[3]) * dist);            /* :322,:331 */
+            alpha *= mask[r * S + s];                                         /* :332 */
+            if (alpha > amax) { amax = alpha; arg = s; }                      /* :340 */
+            const float w = alpha * T;                                        /* :334-338 */
+            T *= 1.0f - alpha + 1e-10f;
+            for (int k = 0; k < 3; k++) c[k] += w * oc_sigmoid(rw[k]);
+            depth += w * z_vals[r * S + s];
+            acc += w;
+            if (weights_out) weights_out[r * S + s] = w;
+        }
+        for (int k = 0; k < 3; k++) rgb_map[r * 3 + k] = c[k] + (1.0f - acc) * bg[k] / 255.0f;
+        acc_map[r] = acc;
+        depth_map[r] = depth;
+        if (term_point) term_point[r] = arg;
+    }
+}
+
+OC_EXPORT int oc_version(void) { return 1; }

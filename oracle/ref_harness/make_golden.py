@@ -1,0 +1,271 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference on CPU.
+
+Build-container only (needs /root/reference); run as
+    python oracle/ref_harness/make_golden.py
+The reference's Python source never leaves this container: only the arrays it consumes
+and produces are stored (inputs, per-stage intermediates, final outputs), together with
+SHA-256 digests of the seeded checkpoint tensors (occnerf_amd/checkpoint.py recipe).
+
+Stages recorded per case (SURVEY.md section 8(a) row in brackets):
+  frame inputs [a1]; pose decoder / motion bases / motion-weight volume [a2-a4];
+  _sample_motion_fields in/out [a6,a7]; non-rigid MLP in/out [a9]; every fast_knn call
+  [a10, a11]; GridEncoder in/out [a14]; CanonicalMLP kwargs/out [a13,a15,a16];
+  _raw2outputs in/out [a17]; Network.forward outputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from oracle.ref_harness import shims  # noqa: E402
+
+OUT_DIR = os.path.join(REPO, 'tests', 'golden')
+CASES = sys.argv[1:] or ['all']            # read before shims.install() rewrites sys.argv
+
+cfg = shims.install(['run.py', '--cfg', 'configs/occnerf/zju_mocap/387/occnerf.yaml',
+                     '--type', 'tpose'])
+
+from occnerf_amd import checkpoint, synth  # noqa: E402
+from core.nets import create_network  # noqa: E402  (reference)
+import core.utils.body_util as ref_body  # noqa: E402
+import core.utils.camera_util as ref_cam  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def _np(x):
+    if torch.is_tensor(x):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+class Recorder:
+    def __init__(self):
+        self.d = {}
+        self.counts = {}
+
+    def put(self, name, value, first_only=True):
+        n = self.counts.get(name, 0)
+        self.counts[name] = n + 1
+        if n == 0:
+            self.d[name] = _np(value).copy()
+        elif not first_only:
+            self.d[f'{name}#{n}'] = _np(value).copy()
+
+
+def build_reference_network(seed, amplify):
+    net = create_network()
+    net.generate_neural_points(np.zeros(10, 'float32'))
+    sd = checkpoint.make_state_dict(net.point_base.detach().numpy(), float(net.bound), seed=seed,
+                                    amplify=amplify)
+    net.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+    return net.deploy_mlps_to_secondary_gpus(), sd
+
+
+def instrument(net, rec):
+    """Wrap the reference's stage functions with recorders (no behaviour change)."""
+    netmod = sys.modules[type(net).__module__]
+    Network = type(net)
+
+    orig_smf = Network._sample_motion_fields
+
+    def smf(pts, motion_scale_Rs, motion_Ts, motion_weights_vol, cnl_bbox_min_xyz,
+            cnl_bbox_scale_xyz, output_list):
+        out = orig_smf(pts, motion_scale_Rs, motion_Ts, motion_weights_vol, cnl_bbox_min_xyz,
+                       cnl_bbox_scale_xyz, output_list)
+        rec.put('warp.pts', pts)
+        rec.put('warp.Rs', motion_scale_Rs)
+        rec.put('warp.Ts', motion_Ts)
+        rec.put('warp.vol', motion_weights_vol)
+        rec.put('warp.x_skel', out['x_skel'])
+        rec.put('warp.mask', out['fg_likelihood_mask'])
+        return out
+    Network._sample_motion_fields = staticmethod(smf)
+
+    orig_knn = netmod.fast_knn
+
+    def knn(q, s, k, **kw):
+        out = orig_knn(q, s, k, **kw)
+        tag = 'msknn' if kw.get('ranges_x') is not None else f'knn{k}'
+        rec.put(f'{tag}.q', q)
+        rec.put(f'{tag}.s', s)
+        rec.put(f'{tag}.idx', out)
+        return out
+    netmod.fast_knn = knn
+
+    orig_r2o = Network._raw2outputs
+
+    def r2o(raw, raw_mask, z_vals, rays_d, bgcolor=None):
+        out = orig_r2o(raw, raw_mask, z_vals, rays_d, bgcolor)
+        rec.put('comp.raw', raw)
+        rec.put('comp.mask', raw_mask)
+        rec.put('comp.z_vals', z_vals)
+        rec.put('comp.rays_d', rays_d)
+        for n, v in zip(('rgb', 'acc', 'weights', 'depth', 'term'), out):
+            rec.put('comp.' + n, v)
+        return out
+    Network._raw2outputs = staticmethod(r2o)
+
+    cm = net.cnl_mlp.module
+    orig_cm = cm.forward
+
+    def cmf(**kw):
+        for n in ('xyz', 'knn_points', 'point_norms', 'point_cloud', 'point_sdf', 'knn_idxs',
+                  'learnable_points'):
+            rec.put('cnl.' + n, kw[n])
+        rec.put('cnl.knn_att', kw['knn_att'].clone())       # simple_agg mutates it in place
+        out = orig_cm(**kw)
+        rec.put('cnl.raw', out)
+        return out
+    cm.forward = cmf
+
+    enc = cm.encoder
+    orig_enc = enc.forward
+    state = {'n': 0}
+
+    def encf(inputs, bound=1):
+        out = orig_enc(inputs, bound=bound)
+        tag = 'enc_sample' if state['n'] % 2 == 0 else 'enc_point'
+        state['n'] += 1
+        rec.put(tag + '.in', inputs)
+        rec.put(tag + '.out', out)
+        return out
+    enc.forward = encf
+
+    nr = net.non_rigid_mlp.module
+    orig_nr = nr.forward
+
+    def nrf(pos_embed, pos_xyz, condition_code, **kw):
+        out = orig_nr(pos_embed=pos_embed, pos_xyz=pos_xyz, condition_code=condition_code, **kw)
+        rec.put('nr.embed', pos_embed)
+        rec.put('nr.xyz_in', pos_xyz)
+        rec.put('nr.cond', condition_code[:1])
+        rec.put('nr.xyz_out', out['xyz'])
+        return out
+    nr.forward = nrf
+
+    def h_pose(m, i, o):
+        rec.put('pose.Rs', o['Rs'])
+
+    def h_vol(m, i, o):
+        rec.put('mw.vol', o)
+
+    def h_mb(m, i, o):
+        rec.put('mb.Rs', o[0])
+        rec.put('mb.Ts', o[1])
+    net.pose_decoder.register_forward_hook(h_pose)
+    net.mweight_vol_decoder.register_forward_hook(h_vol)
+    net.motion_basis_computer.register_forward_hook(h_mb)
+
+    def restore():
+        Network._sample_motion_fields = staticmethod(orig_smf)
+        Network._raw2outputs = staticmethod(orig_r2o)
+        netmod.fast_knn = orig_knn
+    return restore
+
+
+def check_inputs_against_reference(frame, img_size, pose):
+    """The synthetic frame generator must agree with the reference's own numpy helpers."""
+    cj = synth.tpose_joints(np.zeros(10)).astype('float32')
+    Rs, Ts = ref_body.body_pose_to_body_RTs(pose.copy(), cj)
+    assert np.allclose(Rs, frame['dst_Rs'], atol=1e-6) and np.array_equal(Ts, frame['dst_Ts'])
+    assert np.array_equal(ref_body.get_canonical_global_tfms(cj), frame['cnl_gtfms'])
+    bb = synth.skeleton_to_bbox(cj)
+    pr = ref_body.approx_gaussian_bone_volumes(cj, bb['min_xyz'], bb['max_xyz'],
+                                               grid_size=32).astype('float32')
+    assert np.allclose(pr, frame['motion_weights_priors'], atol=2e-6), \
+        np.abs(pr - frame['motion_weights_priors']).max()
+
+
+def run_case(name, img_size, S, amplify, pose=None, orbit_frame=0, non_rigid=False, seed=0,
+             keep_rays=None):
+    print(f'== {name}: {img_size}x{img_size}, S={S}, amplify={amplify}, non_rigid={non_rigid}')
+    cfg.N_samples = S
+    cfg.perturb = 0.
+    cfg.ignore_non_rigid_motions = not non_rigid
+    cfg.chunk = 32768
+    pose72 = np.zeros(72, 'float32') if pose is None else pose
+    frame = synth.make_frame(img_size=img_size, pose72=pose72, orbit_frame=orbit_frame)
+    check_inputs_against_reference(frame, img_size, pose72)
+    if keep_rays is not None:                       # thin the ray set, keep a spread
+        R = frame['rays'].shape[1]
+        sel = np.linspace(0, R - 1, keep_rays).astype(np.int64)
+        frame['rays'] = frame['rays'][:, sel]
+        frame['near'], frame['far'] = frame['near'][sel], frame['far'][sel]
+        frame['ray_select'] = sel
+
+    net, sd = build_reference_network(seed, amplify)
+    net.eval()
+    rec = Recorder()
+    restore = instrument(net, rec)
+    tkeys = ['rays', 'near', 'far', 'bgcolor', 'dst_Rs', 'dst_Ts', 'cnl_gtfms',
+             'motion_weights_priors', 'cnl_bbox_min_xyz', 'cnl_bbox_max_xyz',
+             'cnl_bbox_scale_xyz', 'dst_posevec']
+    data = {k: torch.from_numpy(np.ascontiguousarray(frame[k])) for k in tkeys}
+    with torch.no_grad():
+        out = net(**data, iter_val=cfg.eval_iter)
+    restore()
+
+    g = {'meta.img_size': img_size, 'meta.S': S, 'meta.amplify': int(amplify),
+         'meta.non_rigid': int(non_rigid), 'meta.seed': seed, 'meta.bound': float(net.bound),
+         'meta.orbit_frame': orbit_frame, 'meta.pose72': pose72}
+    for k in tkeys + ['ray_mask'] + (['ray_select'] if keep_rays is not None else []):
+        if k != 'motion_weights_priors':            # regenerable (synth), 3.3 MB
+            g['in.' + k] = frame[k]
+    n_smp = rec.d['cnl.xyz'].shape[0]
+    # derivable entries are checked here and not stored
+    assert np.array_equal(rec.d['msknn.q'], np.tile(rec.d['cnl.xyz'], (4, 1)))
+    pb = sd['point_base'].numpy()
+    assert np.array_equal(rec.d['cnl.knn_points'],
+                          pb[rec.d['cnl.knn_idxs'][:, 0]].reshape(n_smp, 10, 3))
+    assert np.array_equal(rec.d['cnl.point_norms'],
+                          _np(net.point_norms)[rec.d['cnl.knn_idxs'][:, 0]].reshape(n_smp, 10, 3))
+    assert np.array_equal(rec.d['cnl.knn_att'][..., 0],
+                          sd['point_counter'].numpy()[rec.d['cnl.knn_idxs']].reshape(n_smp, 40))
+    skip = ('warp.vol', 'mw.vol',                    # 3.3 MB each; slices + sum kept below
+            'msknn.q', 'msknn.s', 'knn3.q', 'knn3.s', 'cnl.knn_points', 'cnl.point_norms',
+            'cnl.knn_att')
+    for k, v in rec.d.items():
+        if k not in skip:
+            g[k] = v
+    vol = rec.d['mw.vol']
+    g['mw.vol_slice'] = vol[0, :, ::4, ::4, ::4].copy()
+    g['mw.vol_sum'] = np.float64(vol.astype(np.float64).sum())
+    for k in ('rgb', 'alpha', 'depth'):
+        g['out.' + k] = _np(out[k])
+    g['model.fps0'], g['model.fps1'], g['model.fps2'] = [_np(f) for f in net.fps_index]
+    g['model.point_norms_digest'] = checkpoint.tensor_digest(net.point_norms)
+    g['model.ranges_y'] = _np(net.ranges_y)
+    g['sd.keys'] = np.array(list(sd.keys()))
+    g['sd.digests'] = np.array([checkpoint.tensor_digest(v) for v in sd.values()])
+    # int16 is enough for point indices; halves the biggest arrays
+    for k in list(g.keys()):
+        if k.endswith('.idx') or k == 'cnl.knn_idxs':
+            assert g[k].max() < 32768
+            g[k] = g[k].astype(np.int16)
+    path = os.path.join(OUT_DIR, name + '.npz')
+    np.savez_compressed(path, **g)
+    print('   rays', frame['rays'].shape[1], '-> wrote', path,
+          f'{os.path.getsize(path) / 1e6:.2f} MB;',
+          'rgb range', float(out['rgb'].min()), float(out['rgb'].max()),
+          'alpha max', float(out['alpha'].max()))
+    return g
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT_DIR, exist_ok=True)
+    which = CASES
+    if 'all' in which or 'tpose' in which:
+        run_case('tpose_ri_s32', img_size=32, S=32, amplify=False, keep_rays=160)
+    if 'all' in which or 'tpose128' in which:
+        run_case('tpose_ri_s128', img_size=32, S=128, amplify=False, keep_rays=48)
+    if 'all' in which or 'freeview' in which:
+        run_case('freeview_amp_s32', img_size=32, S=32, amplify=True, pose=synth.seeded_pose(1),
+                 orbit_frame=28, non_rigid=True, keep_rays=160)
+    if 'all' in which or 'tposeamp' in which:
+        run_case('tpose_amp_s32', img_size=32, S=32, amplify=True, keep_rays=160)
