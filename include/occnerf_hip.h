@@ -1,0 +1,181 @@
+/*
+ * occnerf_hip.h -- C ABI of the MI355X (gfx950) implementation of OccNeRF's per-ray
+ * volumetric rendering hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with h_ (host);
+ *   - caller owns all buffers, outputs are caller-allocated (the reference's FFI
+ *     convention, gridencoder/src/gridencoder.cu:448-503);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are
+ *     asynchronous, nothing here synchronises;
+ *   - return value: 0 on success, non-zero on error (invalid argument or a HIP error);
+ *     occnerf_last_error() returns a thread-local description.  The Python host layer
+ *     turns a non-zero return into RuntimeError, matching the reference's TORCH_CHECK
+ *     -> c10::Error -> RuntimeError behaviour (gridencoder.cu:15-18).
+ *
+ * Section 1 is the reference's own native operator interface for this path (the
+ * `_gridencoder` pybind module).  Section 2 are the fused stages that sit behind the
+ * reference's *module* seam (core/nets/occnerf/network.py `Network`,
+ * canonical_mlps/occnerf_mlp.py `CanonicalMLP`): the reference evaluates them as chains
+ * of torch ops and has no FFI for them; each entry cites the Python it replaces.
+ */
+#ifndef OCCNERF_HIP_H
+#define OCCNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCCNERF_ABI_VERSION 1
+
+int occnerf_abi_version(void);
+const char *occnerf_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * 1. Grid encoder -- replaces core/nets/occnerf/gridencoder/src/bindings.cpp:5-9
+ *    (prototypes gridencoder.h:12-15, kernels gridencoder.cu:87-369,506-645).
+ *    Argument order and meaning are the reference's; at::Tensor -> pointer, and the
+ *    trailing stream is new (the reference launches on the legacy default stream).
+ *    D in {2,3,4,5}, C in {1,2,4,8}, fp32 embeddings (the dtype the path uses).
+ * ---------------------------------------------------------------------------------- */
+
+/* inputs[B,D] in [0,1] (rows outside -> zeros); embeddings[sO,C]; offsets[L+1] int32;
+ * outputs[L,B,C] written in place; dy_dx[B,L*D*C] or NULL.
+ * S = log2(per_level_scale), H = base resolution, gridtype 0 hash / 1 tiled,
+ * interp 0 linear / 1 smoothstep.                         gridencoder.cu:448-471 */
+int occnerf_grid_encode_forward(const float *inputs, const float *embeddings,
+                                const int32_t *offsets, float *outputs, uint32_t B, uint32_t D,
+                                uint32_t C, uint32_t L, float S, uint32_t H, float *dy_dx,
+                                uint32_t gridtype, int align_corners, uint32_t interp,
+                                void *stream);
+
+/* grad[L,B,C]; grad_embeddings[sO,C] must be zero-filled by the caller and is
+ * accumulated with fp32 atomics; dy_dx / grad_inputs[B,D] optional (both or neither).
+ *                                                          gridencoder.cu:473-503 */
+int occnerf_grid_encode_backward(const float *grad, const float *inputs, const float *embeddings,
+                                 const int32_t *offsets, float *grad_embeddings, uint32_t B,
+                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                 const float *dy_dx, float *grad_inputs, uint32_t gridtype,
+                                 int align_corners, uint32_t interp, void *stream);
+
+/* Total-variation gradient, gridencoder.cu:506-645.  Never called by the reference's
+ * trainer; exported for interface completeness and
+ * returns an error ("not implemented") without touching its arguments. */
+int occnerf_grad_total_variation(const float *inputs, const float *embeddings, float *grad,
+                                 const int32_t *offsets, float weight, uint32_t B, uint32_t D,
+                                 uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                 int align_corners, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * 2. Sample pipeline (behind Network.forward / CanonicalMLP.forward)
+ * ---------------------------------------------------------------------------------- */
+
+/* Ray sampling + backward warp to canonical space.
+ * Replaces network.py:405-432 (_unpack_ray_batch, _get_samples_along_ray,
+ * _stratified_sampling), :456 (pts) and :351-402 (_sample_motion_fields).
+ * rays[n,8] = (o, d, near, far); t_vals[S] = linspace(0,1,S); t_rand[n,S] or NULL;
+ * Rs[nb,3,3], Ts[nb,3]: motion bases; vol[>=nb,G,G,G]: motion-weight volume (a trailing
+ * background channel is ignored); h_bbox_min[3], h_bbox_scale[3] on the HOST.
+ * Outputs z_vals[n,S], x_skel[n*S,3], mask[n*S]; pts[n*S,3] optional (NULL to skip). */
+int occnerf_sample_warp(const float *rays, int64_t n, int32_t S, const float *t_vals,
+                        const float *t_rand, const float *Rs, const float *Ts, const float *vol,
+                        int32_t nb, int32_t G, const float *h_bbox_min, const float *h_bbox_scale,
+                        float *z_vals, float *pts, float *x_skel, float *mask, void *stream);
+
+/* Non-rigid offset MLP (105 -> 128 x6 (skip @4) -> 3) with the Hann-windowed Fourier
+ * embedding.  Replaces embedders/hannw_fourier.py:9-63 + mlp_offset.py:45-62 as called at
+ * network.py:225-232.
+ * occnerf_nonrigid_pack: h_W/h_b = HOST arrays of the 7 device weight/bias pointers
+ * (block_mlps.{0,2,...,12}, torch layout) -> packed[occnerf_nonrigid_packed_floats()], once
+ * per checkpoint.  occnerf_nonrigid: cond[69] is the frame's condition code (folded into the
+ * layer-0 bias inside `packed`, which is therefore written per call), W0/b0 the layer-0
+ * weight/bias, h_hann[6] the HOST window weights.  xyz_out may alias xyz_in. */
+int64_t occnerf_nonrigid_packed_floats(void);
+int occnerf_nonrigid_pack(const float *const *h_W, const float *const *h_b, float *packed,
+                          void *stream);
+int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
+                     const float *W0, const float *b0, float *packed, float *xyz_out,
+                     void *stream);
+
+/* Multi-scale exact kNN (k = 10, up to 4 point sets).  Replaces the pykeops
+ * Kmin_argKmin reduction of knn.py:77-85 and the index bookkeeping of network.py:235-255.
+ * points[M,3]: the scales concatenated (scale 0 = all base points first);
+ * h_scale_begin[nscale+1] host prefix offsets into points; index_map[M]: base-point index
+ * of every row (identity for scale 0, fps_index for the others);
+ * h_seed_from_coarser[nscale]: non-zero when scale s is a superset of scale s+1, which lets
+ * the search bound its radius by the coarser result (results are identical either way).
+ * knn_idxs[N,nscale,10] int32, ascending distance, ties -> lower row first. */
+int occnerf_msknn(const float *xyz, int64_t N, const float *points, const int32_t *index_map,
+                  const int32_t *h_scale_begin, const int32_t *h_seed_from_coarser,
+                  int32_t nscale, int32_t *knn_idxs, void *stream);
+
+/* Plain exact kNN for small problems (k <= 16): idx[nq,k] rows of s, ascending.
+ * Used for the per-point k=3 search of network.py:265-269 and the k=10 visibility update
+ * of network.py:508-512. */
+int occnerf_knn_small(const float *q, int32_t nq, const float *s, int32_t ns, int32_t k,
+                      int32_t *idx, void *stream);
+
+/* unit[P,3] = normals / max(|normals|, 1e-8) in float64: the normal-side half of
+ * F.cosine_similarity (network.py:275, occnerf_mlp.py:165).  A per-model constant, computed
+ * once after generate_neural_points and passed to the two functions below. */
+int occnerf_unit_normals(const double *normals, int32_t P, double *unit, void *stream);
+
+/* Per-point signed-distance block, network.py:263-284 (chunk-invariant; once per frame).
+ * point_cloud[P,3] = point_base + point_dist; normals[P,3] float64; kidx[P,3] from
+ * occnerf_knn_small.  Outputs knn_base[P,3] float64, dist[P] fp32. */
+int occnerf_point_sdf(const float *point_cloud, const float *point_base, const double *normals,
+                      const double *unit_normals, const int32_t *kidx, int32_t P,
+                      double *knn_base, float *dist, void *stream);
+
+/* Per-point feature table, occnerf_mlp.py:171-175:
+ * table[P,36] = [encode((knn_base+bound)/(2 bound), clamp((sdf+0.2)/0.8,0,1)) (32),
+ *                learnable xyz (3), 0]  (row padded to 36 floats = 144 B). */
+int occnerf_point_table(const double *knn_base, const float *point_sdf, const float *learnable,
+                        int32_t P, float bound, float two_bound, const float *embeddings,
+                        const int32_t *offsets, uint32_t L, float S, uint32_t H, float *table,
+                        void *stream);
+
+/* Per-sample features: neighbour geometry + hash encoding + visibility-softmax
+ * aggregation.  Replaces occnerf_mlp.py:144-181 (+ simple_agg :86-126).
+ * knn_idxs[N,nscale,10]: base-point rows; counter[P] visibility counts; table from
+ * occnerf_point_table.  Outputs mlp_in[N,68] = [agg(35), var(1), enc(32)] and raw[N,5]
+ * column 4 (signed distance); enc_in[N,4] optional (NULL to skip).
+ * Two optional inputs serve callers that hold the reference's *gathered* CanonicalMLP
+ * arguments instead of per-point arrays: geo_idxs[N,10] (rows of point_base/normals to use
+ * for the geometry prelude instead of knn_idxs[:,0,:]) and att_in[N,nscale*10] (visibility
+ * counts already gathered, used instead of counter[knn_idxs]); NULL for the normal path. */
+int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs, int32_t nscale,
+                            const float *point_base, const double *normals,
+                            const double *unit_normals, const float *counter,
+                            const float *table, float bound, float two_bound,
+                            const float *embeddings, const int32_t *offsets, uint32_t L, float S,
+                            uint32_t H, const int32_t *geo_idxs, const float *att_in,
+                            float *mlp_in, float *raw, float *enc_in, void *stream);
+
+/* Canonical MLP weights -> MFMA operand order.  h_W/h_b: HOST arrays of the 10 device
+ * weight/bias pointers in module order: pts_linears.{0,2,4,6}, geo_linear.0,
+ * rgb_linears.{0,2,4,6}, output_linear.0 (torch layout [out,in]).  packed: device buffer of
+ * occnerf_canonical_mlp_packed_floats() floats.  Only mlp_depth = 4, mlp_width = 256
+ * (configs/occnerf/zju_mocap/387/occnerf.yaml:16-21) is built. */
+int64_t occnerf_canonical_mlp_packed_floats(void);
+int occnerf_canonical_mlp_pack(const float *const *h_W, const float *const *h_b, float *packed,
+                               void *stream);
+
+/* Geometry + colour trunks on fp32 MFMA.  Replaces occnerf_mlp.py:183-199.
+ * mlp_in[N,68] -> raw[N,5] columns 0..3 (rgb logits, sigma); column 4 is left alone. */
+int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *packed, float *raw,
+                          void *stream);
+
+/* Alpha compositing, network.py:320-348.  raw[n,S,5], mask[n*S], z_vals[n,S],
+ * rays[n,8] (direction at floats 3..5), h_bgcolor[3] host, 0..255.
+ * Outputs rgb[n,3], acc[n], depth[n]; weights[n,S] and term[n] (argmax alpha) optional. */
+int occnerf_composite(const float *raw, const float *mask, const float *z_vals, const float *rays,
+                      const float *h_bgcolor, int64_t n, int32_t S, float *rgb, float *acc,
+                      float *depth, float *weights, int32_t *term, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCCNERF_HIP_H */

@@ -1,0 +1,68 @@
+"""ctypes binding of liboccnerf_hip.so (the C ABI declared in include/occnerf_hip.h).
+
+There is no CPU or eager-torch fallback: if the library is missing the import of any
+op fails with an explicit error, and every op refuses non-GPU tensors.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liboccnerf_hip.so')
+
+_vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
+
+# name -> (restype, argtypes); mirrors include/occnerf_hip.h one to one
+SIGNATURES = {
+    'occnerf_abi_version': (C.c_int, []),
+    'occnerf_last_error': (C.c_char_p, []),
+    'occnerf_grid_encode_forward': (C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32,
+                                               _vp, _u32, C.c_int, _u32, _vp]),
+    'occnerf_grid_encode_backward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
+                                                _u32, _vp, _vp, _u32, C.c_int, _u32, _vp]),
+    'occnerf_grad_total_variation': (C.c_int, [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32,
+                                                _u32, _u32, C.c_int, _vp]),
+    'occnerf_sample_warp': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
+                                       _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_nonrigid_packed_floats': (_i64, []),
+    'occnerf_nonrigid_pack': (C.c_int, [_vp, _vp, _vp, _vp]),
+    'occnerf_nonrigid': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_msknn': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    'occnerf_knn_small': (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    'occnerf_unit_normals': (C.c_int, [_vp, _i32, _vp, _vp]),
+    'occnerf_point_sdf': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    'occnerf_point_table': (C.c_int, [_vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _u32, _f32, _u32, _vp,
+                                       _vp]),
+    'occnerf_sample_features': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp,
+                                           _vp, _u32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_canonical_mlp_packed_floats': (_i64, []),
+    'occnerf_canonical_mlp_pack': (C.c_int, [_vp, _vp, _vp, _vp]),
+    'occnerf_canonical_mlp': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    'occnerf_composite': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f'{LIB_PATH} not found: the gfx950 kernels are not built. Run '
+                '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C '
+                'occnerf_amd/csrc`). There is no CPU fallback for this path.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)            # AttributeError if the ABI drifted
+            fn.restype, fn.argtypes = res, args
+        if handle.occnerf_abi_version() != 1:
+            raise ImportError('liboccnerf_hip.so: ABI version mismatch')
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().occnerf_last_error().decode(errors='replace')
+        raise RuntimeError(f'{what} failed ({rc}): {msg}')

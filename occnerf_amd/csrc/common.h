@@ -1,0 +1,119 @@
+// Shared host/device helpers for the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/occnerf_hip.h"
+
+#define OCC_API extern "C" __attribute__((visibility("default")))
+
+namespace occ {
+
+constexpr int kWave = 64;       // CDNA wavefront
+constexpr int kNumCU = 256;     // MI355X
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return 2;
+    }
+    return 0;
+}
+
+#define OCC_REQUIRE(cond, ...)         \
+    do {                               \
+        if (!(cond)) {                 \
+            occ::set_error(__VA_ARGS__); \
+            return 1;                  \
+        }                              \
+    } while (0)
+
+// ---- multi-resolution grid: per-level constants computed on the HOST so that device
+// exp2f accuracy never enters the result (oracle: oc_grid_level_params) ---------------
+constexpr int kMaxLevels = 16;
+
+struct GridLevels {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+};
+
+GridLevels make_grid_levels(uint32_t L, float S, uint32_t H);
+
+// gridencoder.cu:50-84: dense index while the stride fits, xor-prime hash otherwise;
+// uint32 wrap-around arithmetic throughout.
+template <uint32_t D>
+__device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align_corners,
+                                               uint32_t hashmap_size, uint32_t resolution,
+                                               const uint32_t (&pos_grid)[D]) {
+    constexpr uint32_t primes[7] = {1u,          2654435761u, 805459861u, 3674653429u,
+                                    2097192037u, 1434869437u, 2165219737u};
+    uint32_t stride = 1, index = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += pos_grid[d] * stride;
+            stride *= align_corners ? resolution : (resolution + 1);
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) {
+        uint32_t h = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) h ^= pos_grid[d] * primes[d];
+        index = h;
+    }
+    return index % hashmap_size;
+}
+
+// One level of the D=4, C=2 encoder used by the canonical MLP (occnerf_mlp.py:45):
+// 16 corners, float2 features, explicit fma chain in corner order (bit-exact with the
+// oracle's oc_grid_encode_one).  `grid` points at this level's slice of the table.
+__device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const float2 *grid,
+                                                    uint32_t hashmap_size, float scale,
+                                                    uint32_t resolution) {
+    float pos[4];
+    uint32_t pg[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        pos[d] = __fmaf_rn(x[d], scale, 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= fl;
+    }
+    float2 r = make_float2(0.f, 0.f);
+#pragma unroll
+    for (uint32_t idx = 0; idx < 16; idx++) {
+        float w = 1.f;
+        uint32_t pl[4];
+#pragma unroll
+        for (uint32_t d = 0; d < 4; d++) {
+            if ((idx & (1u << d)) == 0) {
+                w = __fmul_rn(w, __fsub_rn(1.f, pos[d]));
+                pl[d] = pg[d];
+            } else {
+                w = __fmul_rn(w, pos[d]);
+                pl[d] = pg[d] + 1;
+            }
+        }
+        const uint32_t index = grid_index<4>(0, false, hashmap_size, resolution, pl);
+        const float2 v = grid[index];
+        r.x = __fmaf_rn(w, v.x, r.x);
+        r.y = __fmaf_rn(w, v.y, r.y);
+    }
+    return r;
+}
+
+// torch's fp32 2-norm of a 3-vector: sqrt(fma(z,z,fma(y,y,x*x))) (oracle: oc_norm3)
+__device__ __forceinline__ float norm3(float x, float y, float z) {
+    return __fsqrt_rn(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+}
+
+}  // namespace occ

@@ -1,0 +1,325 @@
+// Per-point and per-sample feature stages of CanonicalMLP (SURVEY.md section 8 rows a11,
+// a13, a14, a15).
+//
+//  point_sdf_kernel     network.py:263-284   once per frame over the P = 6890 body points
+//  point_table_kernel   occnerf_mlp.py:171-175  per-point [hash encoding(32), learnable xyz(3)]
+//  sample_features      occnerf_mlp.py:144-181  per sample: neighbour geometry (fp64 where the
+//                       reference's float64 normals promote it), 4-D hash encoding, gather of
+//                       40 table rows + visibility softmax -> the MLP's 68 inputs
+//
+// The reference recomputes the per-point block for every 300 000-sample chunk (112x per
+// 512^2 frame); it only depends on the weights, so it is hoisted to once per frame.
+//
+// sample_features is gather-bound (L2 / Infinity Cache): algorithmic bytes per sample =
+// 16 levels x 16 corners x 8 B (hash table, 59 MiB) + 40 rows x 140 B (point table, 0.97 MB,
+// L2-resident) + 10 x (12 + 24) B neighbour positions/normals + 160 B of indices in;
+// 272 + 4 B out.  Arithmetic mirrors the oracle operation for operation (explicit
+// __f*_rn / __d*_rn, no contraction) so that encoder inputs are bit-identical to it.
+#include "common.h"
+
+namespace occ {
+
+constexpr int kKnn = 10;
+constexpr int kTableStride = 36;   // 35 features padded to 36 floats (16-byte rows)
+
+// F.cosine_similarity(float32 dir, float64 normal): dir normalised in fp32, normal in fp64,
+// products in fp64 (oracle: oc_cos3).  `un` is the pre-normalised fp64 normal b / max(|b|,eps).
+__device__ __forceinline__ double cos3_unit(const float (&a)[3], const double *__restrict__ un) {
+    float na = norm3(a[0], a[1], a[2]);
+    na = na < 1e-8f ? 1e-8f : na;
+    const double t0 = __dmul_rn((double)__fdiv_rn(a[0], na), un[0]);
+    const double t1 = __dmul_rn((double)__fdiv_rn(a[1], na), un[1]);
+    const double t2 = __dmul_rn((double)__fdiv_rn(a[2], na), un[2]);
+    return __dadd_rn(__dadd_rn(t0, t1), t2);
+}
+
+// unit[P,3] = n / max(|n|, 1e-8) in fp64, the x2 half of torch's cosine_similarity;
+// constant per model, computed once.
+__global__ void unit_normals_kernel(const double *__restrict__ normals, int P,
+                                    double *__restrict__ unit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const double b0 = normals[i * 3], b1 = normals[i * 3 + 1], b2 = normals[i * 3 + 2];
+    double nb = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(b0, b0), __dmul_rn(b1, b1)), __dmul_rn(b2, b2)));
+    nb = nb < 1e-8 ? 1e-8 : nb;
+    unit[i * 3] = __ddiv_rn(b0, nb);
+    unit[i * 3 + 1] = __ddiv_rn(b1, nb);
+    unit[i * 3 + 2] = __ddiv_rn(b2, nb);
+}
+
+__global__ void point_sdf_kernel(const float *__restrict__ point_cloud,
+                                 const float *__restrict__ point_base,
+                                 const double *__restrict__ normals,
+                                 const double *__restrict__ unit, const int32_t *__restrict__ kidx,
+                                 int P, double *__restrict__ knn_base, float *__restrict__ dist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    double num[3] = {0.0, 0.0, 0.0}, den = 0.0;
+    float dsum = 0.0f;
+    int neg = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int n = kidx[i * 3 + j];
+        float dir[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) dir[c] = __fsub_rn(point_cloud[i * 3 + c], point_base[n * 3 + c]);
+        const double att = fabs(cos3_unit(dir, unit + (size_t)n * 3));           // network.py:275
+#pragma unroll
+        for (int c = 0; c < 3; c++) num[c] = __dadd_rn(num[c], __dmul_rn(att, (double)point_base[n * 3 + c]));
+        den = __dadd_rn(den, att);
+        const float n0 = (float)normals[n * 3], n1 = (float)normals[n * 3 + 1], n2 = (float)normals[n * 3 + 2];
+        const float dot = __fadd_rn(__fadd_rn(__fmul_rn(dir[0], n0), __fmul_rn(dir[1], n1)), __fmul_rn(dir[2], n2));
+        neg += dot < 0.0f;                                                       // :278
+        dsum = __fadd_rn(dsum, norm3(dir[0], dir[1], dir[2]));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) knn_base[i * 3 + c] = __ddiv_rn(num[c], den);    // :276
+    float d = __fdiv_rn(dsum, 3.0f);                                             // :281
+    if (neg > 1) d = -d;                                                         // :279,:282
+    dist[i] = d;
+}
+
+__global__ void point_table_kernel(const double *__restrict__ knn_base,
+                                   const float *__restrict__ point_sdf,
+                                   const float *__restrict__ learnable, int P, float bound,
+                                   float two_bound, const float2 *__restrict__ embeddings,
+                                   const int32_t *__restrict__ offsets, int L, GridLevels lv,
+                                   float *__restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float x[4];
+#pragma unroll
+    for (int c = 0; c < 3; c++)                                                  // occnerf_mlp.py:171
+        x[c] = (float)__ddiv_rn(__dadd_rn(knn_base[i * 3 + c], (double)bound), (double)two_bound);
+    float s = __fdiv_rn(__fadd_rn(point_sdf[i], 0.2f), 0.8f);                    // :172
+    x[3] = s < 0.0f ? 0.0f : (s > 1.0f ? 1.0f : s);
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < 4; d++) oob |= (x[d] < 0.f || x[d] > 1.f);
+    float *row = table + (size_t)i * kTableStride;
+    for (int l = 0; l < L; l++) {
+        float2 v = make_float2(0.f, 0.f);
+        if (!oob) {
+            const uint32_t o0 = (uint32_t)offsets[l];
+            v = encode_level_d4c2(x, embeddings + o0, (uint32_t)offsets[l + 1] - o0, lv.scale[l],
+                                  lv.resolution[l]);
+        }
+        row[l * 2] = v.x;
+        row[l * 2 + 1] = v.y;
+    }
+    for (int l = L; l < 16; l++) row[l * 2] = row[l * 2 + 1] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) row[32 + c] = learnable[i * 3 + c];
+    row[35] = 0.0f;
+}
+
+struct FeatParams {
+    float bound, two_bound;
+    int nscale, L;
+};
+
+__global__ __launch_bounds__(256) void sample_features_kernel(
+    const float *__restrict__ xyz, int64_t N, const int32_t *__restrict__ knn_idxs,
+    const float *__restrict__ point_base, const double *__restrict__ normals,
+    const double *__restrict__ unit, const float *__restrict__ counter,
+    const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
+    const int32_t *__restrict__ offsets, GridLevels lv, FeatParams prm,
+    const int32_t *__restrict__ geo_idxs, const float *__restrict__ att_in,
+    float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
+    const int nk = prm.nscale * kKnn;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t *id = knn_idxs + i * nk;
+        const float p[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+
+        // ---- neighbour geometry on the finest scale (occnerf_mlp.py:144-167) ----
+        int neg = 0;
+        float dsum = 0.0f;
+        double num[3] = {0.0, 0.0, 0.0}, den = 0.0;
+#pragma unroll
+        for (int j = 0; j < kKnn; j++) {
+            const int n = geo_idxs ? geo_idxs[i * kKnn + j] : id[j];
+            float dir[3], nbr[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                nbr[c] = point_base[n * 3 + c];
+                dir[c] = __fsub_rn(p[c], nbr[c]);                                 // :147
+            }
+            double dot = 0.0;                                                     // :152, fp64
+#pragma unroll
+            for (int c = 0; c < 3; c++) dot = __dadd_rn(dot, __dmul_rn((double)dir[c], normals[(size_t)n * 3 + c]));
+            neg += dot < 0.0;
+            dsum = __fadd_rn(dsum, norm3(dir[0], dir[1], dir[2]));
+            if (j < 3) {                                                          // :164-166
+                const double att = fabs(cos3_unit(dir, unit + (size_t)n * 3));
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float pn = __fdiv_rn(__fadd_rn(nbr[c], prm.bound), prm.two_bound);
+                    num[c] = __dadd_rn(num[c], __dmul_rn(att, (double)pn));
+                }
+                den = __dadd_rn(den, att);
+            }
+        }
+        float dist = __fdiv_rn(dsum, (float)kKnn);                                // :155
+        if (2 * neg > kKnn) dist = -dist;                                         // :153,:156
+        float nd = __fdiv_rn(__fadd_rn(dist, 0.2f), 0.5f);                        // :157
+        nd = nd < 0.0f ? 0.0f : (nd > 1.0f ? 1.0f : nd);
+        float x[4];
+#pragma unroll
+        for (int c = 0; c < 3; c++) x[c] = (float)__ddiv_rn(num[c], den);
+        x[3] = nd;
+        if (enc_in_out) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) enc_in_out[i * 4 + c] = x[c];
+        }
+        raw[i * 5 + 4] = dist;
+
+        float *out = mlp_in + i * 68;
+
+        // ---- 4-D multi-resolution hash encoding (gridencoder.cu:87-199) ----
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 4; d++) oob |= (x[d] < 0.f || x[d] > 1.f);
+        for (int l = 0; l < prm.L; l++) {
+            float2 v = make_float2(0.f, 0.f);
+            if (!oob) {
+                const uint32_t o0 = (uint32_t)offsets[l];
+                v = encode_level_d4c2(x, embeddings + o0, (uint32_t)offsets[l + 1] - o0,
+                                      lv.scale[l], lv.resolution[l]);
+            }
+            *reinterpret_cast<float2 *>(out + 36 + l * 2) = v;
+        }
+
+        // ---- visibility softmax over the 40 multi-scale neighbours (simple_agg :110-125) ----
+        float att[4 * kKnn];
+        float amin = INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4 * kKnn; j++) {
+            att[j] = j < nk ? (att_in ? att_in[i * nk + j] : counter[id[j]]) : INFINITY;
+            amin = fminf(amin, att[j]);
+        }
+        float amax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4 * kKnn; j++) {
+            if (j < nk) {
+                att[j] = __fadd_rn(att[j], __fsub_rn(1.0f, amin));
+                amax = fmaxf(amax, att[j]);
+            }
+        }
+        float mean = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4 * kKnn; j++) {
+            if (j < nk) {
+                att[j] = __fdiv_rn(att[j], amax);
+                mean = __fadd_rn(mean, att[j]);
+            }
+        }
+        mean = __fdiv_rn(mean, (float)nk);
+        float var = 0.0f, smax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4 * kKnn; j++) {
+            if (j < nk) {
+                const float dlt = __fsub_rn(att[j], mean);
+                var = __fadd_rn(var, __fmul_rn(dlt, dlt));
+                smax = fmaxf(smax, att[j]);
+            }
+        }
+        var = __fdiv_rn(var, (float)(nk - 1));                                   // unbiased
+        float ssum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4 * kKnn; j++) {
+            if (j < nk) {
+                att[j] = expf(__fsub_rn(att[j], smax));
+                ssum = __fadd_rn(ssum, att[j]);
+            }
+        }
+        float agg[kTableStride];
+#pragma unroll
+        for (int f = 0; f < kTableStride; f++) agg[f] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4 * kKnn; j++) {   // fully unrolled: att[] must stay in registers
+            if (j < nk) {
+                const float a = __fdiv_rn(att[j], ssum);
+                const float4 *row = table + (size_t)id[j] * (kTableStride / 4);
+#pragma unroll
+                for (int v = 0; v < kTableStride / 4; v++) {
+                    const float4 t = row[v];
+                    agg[v * 4 + 0] = __fadd_rn(agg[v * 4 + 0], __fmul_rn(a, t.x));
+                    agg[v * 4 + 1] = __fadd_rn(agg[v * 4 + 1], __fmul_rn(a, t.y));
+                    agg[v * 4 + 2] = __fadd_rn(agg[v * 4 + 2], __fmul_rn(a, t.z));
+                    agg[v * 4 + 3] = __fadd_rn(agg[v * 4 + 3], __fmul_rn(a, t.w));
+                }
+            }
+        }
+        agg[35] = var;    // mlp input layout: [agg 0..34, var, enc 0..31]
+#pragma unroll
+        for (int v = 0; v < kTableStride / 4; v++)
+            *reinterpret_cast<float4 *>(out + v * 4) =
+                make_float4(agg[v * 4], agg[v * 4 + 1], agg[v * 4 + 2], agg[v * 4 + 3]);
+    }
+}
+
+}  // namespace occ
+
+// The unit normals are a per-model constant; they are cached in a small device buffer
+// owned by the caller: occnerf_point_sdf(...) fills `unit` when asked to.
+OCC_API int occnerf_unit_normals(const double *normals, int32_t P, double *unit, void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(normals && unit, "unit_normals: null argument");
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(unit_normals_kernel, dim3((P + 255) / 256), dim3(256), 0, as_stream(stream), normals, P, unit);
+    return check_launch("unit_normals");
+}
+
+OCC_API int occnerf_point_sdf(const float *point_cloud, const float *point_base,
+                              const double *normals, const double *unit_normals,
+                              const int32_t *kidx, int32_t P, double *knn_base, float *dist,
+                              void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(point_cloud && point_base && normals && unit_normals && kidx && knn_base && dist,
+                "point_sdf: null argument");
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(point_sdf_kernel, dim3((P + 255) / 256), dim3(256), 0, as_stream(stream), point_cloud,
+                       point_base, normals, unit_normals, kidx, P, knn_base, dist);
+    return check_launch("point_sdf");
+}
+
+OCC_API int occnerf_point_table(const double *knn_base, const float *point_sdf,
+                                const float *learnable, int32_t P, float bound, float two_bound,
+                                const float *embeddings, const int32_t *offsets, uint32_t L, float S,
+                                uint32_t H, float *table, void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(knn_base && point_sdf && learnable && embeddings && offsets && table, "point_table: null argument");
+    OCC_REQUIRE(L >= 1 && L <= 16, "point_table: L=%u unsupported", L);
+    if (P <= 0) return 0;
+    const GridLevels lv = make_grid_levels(L, S, H);
+    hipLaunchKernelGGL(point_table_kernel, dim3((P + 255) / 256), dim3(256), 0, as_stream(stream), knn_base,
+                       point_sdf, learnable, P, bound, two_bound, reinterpret_cast<const float2 *>(embeddings),
+                       offsets, (int)L, lv, table);
+    return check_launch("point_table");
+}
+
+OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs,
+                                    int32_t nscale, const float *point_base, const double *normals,
+                                    const double *unit_normals, const float *counter,
+                                    const float *table, float bound, float two_bound,
+                                    const float *embeddings, const int32_t *offsets, uint32_t L,
+                                    float S, uint32_t H, const int32_t *geo_idxs,
+                                    const float *att_in, float *mlp_in, float *raw, float *enc_in,
+                                    void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(xyz && knn_idxs && point_base && normals && unit_normals && (counter || att_in) && table &&
+                    embeddings && offsets && mlp_in && raw, "sample_features: null argument");
+    OCC_REQUIRE(nscale >= 1 && nscale <= 4, "sample_features: nscale=%d unsupported", nscale);
+    OCC_REQUIRE(L == 16, "sample_features: built for the 16-level encoder of occnerf_mlp.py:45 (L=%u)", L);
+    if (N <= 0) return 0;
+    const GridLevels lv = make_grid_levels(L, S, H);
+    FeatParams prm{bound, two_bound, nscale, (int)L};
+    int64_t blocks = (N + 255) / 256;
+    if (blocks > (int64_t)kNumCU * 16) blocks = (int64_t)kNumCU * 16;
+    hipLaunchKernelGGL(sample_features_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, N,
+                       knn_idxs, point_base, normals, unit_normals, counter,
+                       reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),
+                       offsets, lv, prm, geo_idxs, att_in, mlp_in, raw, enc_in);
+    return check_launch("sample_features");
+}

@@ -1,0 +1,292 @@
+// Multi-resolution hash-grid encoder for gfx950: forward (+dy_dx), backward, TV stub.
+//
+// Operator-level replacement of the reference's `_gridencoder` extension
+// (core/nets/occnerf/gridencoder/src/gridencoder.cu:87-369, bindings.cpp:5-9).
+// The sample pipeline does not call these kernels for its 33 M samples per frame -- it
+// uses the fused occ::encode_level_d4c2 inside sample_features.hip -- but the operator is
+// the reference's native seam for this path, and the per-point table build, the training
+// backward and the operator-level parity tests go through it.
+//
+// Bound: HBM/L2 gather.  Algorithmic bytes per (sample, level): 2^D corners x C x 4 B read
+// (D=4,C=2: 128 B) + C x 4 B written; the dense levels 0-1 are L2-resident, a hashed level
+// is a 4 MiB table (= one XCD L2).  Level is the slow grid axis, as in the reference's
+// [L,B,C] output layout, so that concurrently running blocks work on the same level.
+#include "common.h"
+
+namespace occ {
+
+template <uint32_t D, uint32_t C>
+__global__ __launch_bounds__(256) void grid_forward_kernel(
+    const float *__restrict__ inputs, const float *__restrict__ embeddings,
+    const int32_t *__restrict__ offsets, float *__restrict__ outputs, uint32_t B, uint32_t L,
+    GridLevels lv, float *__restrict__ dy_dx, uint32_t gridtype, bool align_corners,
+    uint32_t interp) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+
+    const float *grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+    const float *x = inputs + (size_t)b * D;
+    float *out = outputs + ((size_t)level * B + b) * C;
+    float *dyl = dy_dx ? dy_dx + ((size_t)b * L + level) * D * C : nullptr;
+
+    float xin[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        xin[d] = x[d];
+        oob |= (xin[d] < 0.f || xin[d] > 1.f);
+    }
+    if (oob) {  // gridencoder.cu:118-135: rows outside [0,1] encode to zero
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) out[ch] = 0.f;
+        if (dyl) {
+#pragma unroll
+            for (uint32_t i = 0; i < D * C; i++) dyl[i] = 0.f;
+        }
+        return;
+    }
+
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+
+    float pos[D], pos_deriv[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = __fmaf_rn(xin[d], scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= fl;
+        if (interp == 1) {
+            pos_deriv[d] = __fmul_rn(__fmul_rn(6.f, pos[d]), __fsub_rn(1.0f, pos[d]));
+            pos[d] = __fmul_rn(__fmul_rn(pos[d], pos[d]),
+                               __fsub_rn(3.0f, __fmul_rn(2.0f, pos[d])));
+        } else {
+            pos_deriv[d] = 1.0f;
+        }
+    }
+
+    float results[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) results[ch] = 0.f;
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1.f;
+        uint32_t pl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) {
+                w = __fmul_rn(w, __fsub_rn(1.f, pos[d]));
+                pl[d] = pg[d];
+            } else {
+                w = __fmul_rn(w, pos[d]);
+                pl[d] = pg[d] + 1;
+            }
+        }
+        const uint32_t index = grid_index<D>(gridtype, align_corners, hashmap_size, resolution, pl) * C;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) results[ch] = __fmaf_rn(w, grid[index + ch], results[ch]);
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) out[ch] = results[ch];
+
+    if (dyl) {  // gridencoder.cu:201-244
+#pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            float rg[C];
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) rg[ch] = 0.f;
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float w = scale;
+                uint32_t pl[D];
+#pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                    if ((idx & (1u << nd)) == 0) {
+                        w = __fmul_rn(w, __fsub_rn(1.f, pos[d]));
+                        pl[d] = pg[d];
+                    } else {
+                        w = __fmul_rn(w, pos[d]);
+                        pl[d] = pg[d] + 1;
+                    }
+                }
+                pl[gd] = pg[gd];
+                const uint32_t il = grid_index<D>(gridtype, align_corners, hashmap_size, resolution, pl) * C;
+                pl[gd] = pg[gd] + 1;
+                const uint32_t ir = grid_index<D>(gridtype, align_corners, hashmap_size, resolution, pl) * C;
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++)
+                    rg[ch] = __fmaf_rn(__fmul_rn(w, __fsub_rn(grid[ir + ch], grid[il + ch])),
+                                       pos_deriv[gd], rg[ch]);
+            }
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) dyl[gd * C + ch] = rg[ch];
+        }
+    }
+}
+
+// gridencoder.cu:248-340.  One thread per (sample, level); all C channels of a corner are
+// added by the same thread (C <= 8), fp32 atomics into the zero-initialised gradient table.
+template <uint32_t D, uint32_t C>
+__global__ __launch_bounds__(256) void grid_backward_kernel(
+    const float *__restrict__ grad, const float *__restrict__ inputs,
+    const int32_t *__restrict__ offsets, float *__restrict__ grad_grid, uint32_t B, uint32_t L,
+    GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    float *gg = grad_grid + (size_t)(uint32_t)offsets[level] * C;
+    const float *x = inputs + (size_t)b * D;
+    const float *g = grad + ((size_t)level * B + b) * C;
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float xd = x[d];
+        if (xd < 0.f || xd > 1.f) return;  // gradient stays zero
+        pos[d] = __fmaf_rn(xd, scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= fl;
+        if (interp == 1)
+            pos[d] = __fmul_rn(__fmul_rn(pos[d], pos[d]), __fsub_rn(3.0f, __fmul_rn(2.0f, pos[d])));
+    }
+    float gc[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) gc[ch] = g[ch];
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1.f;
+        uint32_t pl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) {
+                w = __fmul_rn(w, __fsub_rn(1.f, pos[d]));
+                pl[d] = pg[d];
+            } else {
+                w = __fmul_rn(w, pos[d]);
+                pl[d] = pg[d] + 1;
+            }
+        }
+        const uint32_t index = grid_index<D>(gridtype, align_corners, hashmap_size, resolution, pl) * C;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) atomicAdd(&gg[index + ch], __fmul_rn(w, gc[ch]));
+    }
+}
+
+// gridencoder.cu:343-369
+template <uint32_t D, uint32_t C>
+__global__ __launch_bounds__(256) void grid_input_backward_kernel(
+    const float *__restrict__ grad, const float *__restrict__ dy_dx,
+    float *__restrict__ grad_inputs, uint32_t B, uint32_t L) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const float *dy = dy_dx + (size_t)b * L * D * C;
+    float r = 0.f;
+    for (uint32_t l = 0; l < L; l++) {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++)
+            r += grad[((size_t)l * B + b) * C + ch] * dy[(l * D + d) * C + ch];
+    }
+    grad_inputs[t] = r;
+}
+
+template <uint32_t D>
+int launch_forward_c(uint32_t C, const float *in, const float *emb, const int32_t *off, float *out,
+                     uint32_t B, uint32_t L, const GridLevels &lv, float *dy, uint32_t gt, bool ac,
+                     uint32_t interp, hipStream_t st) {
+    const dim3 grid((B + 255) / 256, L), block(256);
+    switch (C) {
+        case 1: hipLaunchKernelGGL((grid_forward_kernel<D, 1>), grid, block, 0, st, in, emb, off, out, B, L, lv, dy, gt, ac, interp); break;
+        case 2: hipLaunchKernelGGL((grid_forward_kernel<D, 2>), grid, block, 0, st, in, emb, off, out, B, L, lv, dy, gt, ac, interp); break;
+        case 4: hipLaunchKernelGGL((grid_forward_kernel<D, 4>), grid, block, 0, st, in, emb, off, out, B, L, lv, dy, gt, ac, interp); break;
+        case 8: hipLaunchKernelGGL((grid_forward_kernel<D, 8>), grid, block, 0, st, in, emb, off, out, B, L, lv, dy, gt, ac, interp); break;
+        default: set_error("GridEncoding: C must be 1, 2, 4, or 8."); return 1;
+    }
+    return check_launch("grid_encode_forward");
+}
+
+template <uint32_t D>
+int launch_backward_c(uint32_t C, const float *grad, const float *in, const int32_t *off, float *gg,
+                      uint32_t B, uint32_t L, const GridLevels &lv, const float *dy, float *gi,
+                      uint32_t gt, bool ac, uint32_t interp, hipStream_t st) {
+    const dim3 grid((B + 255) / 256, L), block(256);
+    const dim3 grid_in((B * D + 255) / 256);
+#define OCC_BWD(CC)                                                                                   \
+    hipLaunchKernelGGL((grid_backward_kernel<D, CC>), grid, block, 0, st, grad, in, off, gg, B, L, lv, \
+                       gt, ac, interp);                                                               \
+    if (dy) hipLaunchKernelGGL((grid_input_backward_kernel<D, CC>), grid_in, block, 0, st, grad, dy, gi, B, L);
+    switch (C) {
+        case 1: OCC_BWD(1) break;
+        case 2: OCC_BWD(2) break;
+        case 4: OCC_BWD(4) break;
+        case 8: OCC_BWD(8) break;
+        default: set_error("GridEncoding: C must be 1, 2, 4, or 8."); return 1;
+    }
+#undef OCC_BWD
+    return check_launch("grid_encode_backward");
+}
+
+}  // namespace occ
+
+OCC_API int occnerf_grid_encode_forward(const float *inputs, const float *embeddings,
+                                        const int32_t *offsets, float *outputs, uint32_t B,
+                                        uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        float *dy_dx, uint32_t gridtype, int align_corners,
+                                        uint32_t interp, void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null tensor");
+    OCC_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward: L=%u unsupported (1..%d)", L, kMaxLevels);
+    if (B == 0) return 0;
+    const GridLevels lv = make_grid_levels(L, S, H);
+    hipStream_t st = as_stream(stream);
+    const bool ac = align_corners != 0;
+    switch (D) {
+        case 2: return launch_forward_c<2>(C, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st);
+        case 3: return launch_forward_c<3>(C, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st);
+        case 4: return launch_forward_c<4>(C, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st);
+        case 5: return launch_forward_c<5>(C, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st);
+        default: set_error("GridEncoding: D must be 2, 3, 4, or 5."); return 1;
+    }
+}
+
+OCC_API int occnerf_grid_encode_backward(const float *grad, const float *inputs,
+                                         const float *embeddings, const int32_t *offsets,
+                                         float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                         uint32_t L, float S, uint32_t H, const float *dy_dx,
+                                         float *grad_inputs, uint32_t gridtype, int align_corners,
+                                         uint32_t interp, void *stream) {
+    using namespace occ;
+    (void)embeddings;
+    OCC_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null tensor");
+    OCC_REQUIRE((dy_dx == nullptr) == (grad_inputs == nullptr),
+                "grid_encode_backward: dy_dx and grad_inputs must be given together");
+    OCC_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L=%u unsupported", L);
+    if (B == 0) return 0;
+    const GridLevels lv = make_grid_levels(L, S, H);
+    hipStream_t st = as_stream(stream);
+    const bool ac = align_corners != 0;
+    switch (D) {
+        case 2: return launch_backward_c<2>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, st);
+        case 3: return launch_backward_c<3>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, st);
+        case 4: return launch_backward_c<4>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, st);
+        case 5: return launch_backward_c<5>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, st);
+        default: set_error("GridEncoding: D must be 2, 3, 4, or 5."); return 1;
+    }
+}
+
+OCC_API int occnerf_grad_total_variation(const float *, const float *, float *, const int32_t *,
+                                         float, uint32_t, uint32_t, uint32_t, uint32_t, float,
+                                         uint32_t, uint32_t, int, void *) {
+    occ::set_error("grad_total_variation: not implemented (never called by the reference trainer; "
+                   "SURVEY.md section 8 row a20)");
+    return 3;
+}

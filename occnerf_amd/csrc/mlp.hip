@@ -1,0 +1,309 @@
+// Canonical density/colour MLP on fp32 MFMA:
+//   geometry trunk  68 -> 256 -> 256 -> 256 -> 256 -> 65   (sigma = row 0)
+//   colour trunk   131 -> 256 -> 256 -> 256 -> 256 -> 3
+// occnerf_mlp.py:183-199, 461 568 MAC = 923 136 FLOP per sample -- the dominant
+// arithmetic of the whole path and the kernel BASELINE.json's roofline is quoted on.
+//
+// Design (CDNA4, v_mfma_f32_32x32x2_f32, exact fp32 = fmaf chain):
+//  * one wave = 32 samples, all ten layers, activations never leave registers.
+//    The layer is computed transposed, D[feature][sample] = W[feature][k] * act[k][sample]:
+//    in the 32x32 C/D layout lane l holds sample l&31 and, in register r, feature
+//    (r&3) + 8*(r>>2) + 4*(l>>5) of a 32-feature block.  For the NEXT layer the B operand
+//    of k-step r wants "k=0 from lanes 0-31, k=1 from lanes 32-63" -- which is exactly
+//    register r of that block (features f and f+4).  So a layer's output registers ARE the
+//    next layer's B operands; only the weights (A operand) have to be stored in the matching
+//    k order, which occnerf_canonical_mlp_pack does once per checkpoint.
+//  * A operand (weights): one float4 per lane per 4 k-steps, laid out [group][out-block]
+//    [lane] so a wave reads 1 KiB contiguous; streamed from L2 with one group (8 KiB) of
+//    register prefetch -- 2048 MFMA cycles of cover for an L2 hit.  All four waves of the
+//    workgroup read the same stream, so L1 absorbs 3 of 4 reads.
+//  * sigma (1 row) and the 3-row colour head are 256-long dot products: VALU fma over the
+//    lane's 128 features + one cross-half shuffle, instead of a 97 %-empty MFMA block.
+//  * 1 wave per SIMD (acc 128 + act 128 + inputs 36 + weight buffers 64 registers).
+//
+// MFMA count per wave: 288 + 3*1024 + 256 + 544 + 3*1024 = 7232 (ideal 7212): 99.7 % of
+// the issued matrix work is algorithmic.  Roofline: fp32 MFMA, 157.3 TFLOP/s.
+#include "common.h"
+
+namespace occ {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWidth = 256;
+constexpr int kOB = kWidth / 32;     // 8 output blocks of 32 features
+constexpr int kInGeo = 68, kInRgb = 131;
+constexpr int kXRegs = 36;           // 34 input k-steps (68 features over two half-waves) + 2 pad
+constexpr int kG_L0Geo = kXRegs / 4;             // 9 groups of 4 k-steps
+constexpr int kG_Hidden = kWidth / 2 / 4;        // 32
+constexpr int kG_L0Rgb = (32 + kXRegs) / 4;      // 17
+
+// packed blob layout, in floats (every offset a multiple of 4 -> 16-byte aligned)
+constexpr int64_t wsz(int groups, int ob) { return (int64_t)groups * ob * 64 * 4; }
+struct Blob {
+    static constexpr int64_t kGeoL0W = 0;
+    static constexpr int64_t kGeoL0B = kGeoL0W + wsz(kG_L0Geo, kOB);
+    static constexpr int64_t kGeoHW = kGeoL0B + kWidth;                      // 3 x (W, B)
+    static constexpr int64_t kHiddenStride = wsz(kG_Hidden, kOB) + kWidth;
+    static constexpr int64_t kGeoHeadW = kGeoHW + 3 * kHiddenStride;
+    static constexpr int64_t kGeoHeadB = kGeoHeadW + wsz(kG_Hidden, 2);
+    static constexpr int64_t kSigmaW = kGeoHeadB + 64;
+    static constexpr int64_t kSigmaB = kSigmaW + kWidth;
+    static constexpr int64_t kRgbL0W = kSigmaB + 4;
+    static constexpr int64_t kRgbL0B = kRgbL0W + wsz(kG_L0Rgb, kOB);
+    static constexpr int64_t kRgbHW = kRgbL0B + kWidth;
+    static constexpr int64_t kOutW = kRgbHW + 3 * kHiddenStride;
+    static constexpr int64_t kOutB = kOutW + 3 * kWidth;
+    static constexpr int64_t kTotal = kOutB + 4;
+};
+
+// ---------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------
+enum LayerKind { kL0Geo = 0, kHidden = 1, kGeoHead = 2, kL0Rgb = 3 };
+
+// feature of the layer's torch-layout input that k-step `t` carries in half-wave `h`
+// (-1: zero weight)
+__host__ __device__ inline int slot_feature(int kind, int t, int h) {
+    const int blk = t >> 4, r = t & 15;
+    const int cd = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // 32x32 C/D row of (reg, half)
+    switch (kind) {
+        case kL0Geo: return t < 34 ? h * 34 + t : -1;
+        case kHidden:
+        case kGeoHead: return cd;
+        case kL0Rgb: {
+            if (t < 32) return cd;                 // geometry features h[1:65] -> inputs 0..63
+            if (t >= 66) return -1;
+            const int m = h * 34 + (t - 32);       // position in [agg35, var, enc32]
+            if (m < 35) return 64 + m;             // aggregated point features
+            if (m == 35) return -1;                // var is not an input of the colour trunk
+            return 64 + 35 + (m - 36);             // hash encoding
+        }
+    }
+    return -1;
+}
+
+// torch-layout output row computed in packed row `row` (-1: padding row)
+__host__ __device__ inline int out_row(int kind, int row, int out_dim) {
+    if (kind == kGeoHead) return row < 64 ? row + 1 : -1;   // row 0 (sigma) handled by dot_rows
+    return row < out_dim ? row : -1;
+}
+
+__global__ void pack_layer_kernel(const float *__restrict__ W, const float *__restrict__ b,
+                                  int kind, int in_dim, int out_dim, int groups, int ob_count,
+                                  float *__restrict__ Wp, float *__restrict__ Bp) {
+    const int total = groups * ob_count * 64 * 4;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int rr = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+        const int ob = rest % ob_count, g = rest / ob_count;
+        const int col = slot_feature(kind, g * 4 + rr, lane >> 5);
+        const int row = out_row(kind, ob * 32 + (lane & 31), out_dim);
+        Wp[e] = (col >= 0 && row >= 0) ? W[(size_t)row * in_dim + col] : 0.0f;
+    }
+    // bias in accumulator order: [ob][q][half][4]
+    const int nb = ob_count * 32;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nb; e += gridDim.x * blockDim.x) {
+        const int rr = e & 3, h = (e >> 2) & 1, q = (e >> 3) & 3, ob = e >> 5;
+        const int row = out_row(kind, ob * 32 + rr + 8 * q + 4 * h, out_dim);
+        Bp[e] = row >= 0 ? b[row] : 0.0f;
+    }
+}
+
+// rows evaluated as VALU dot products: [row][kb][q][half][4], bias appended
+__global__ void pack_rows_kernel(const float *__restrict__ W, const float *__restrict__ b,
+                                 int nrows, float *__restrict__ Wp, float *__restrict__ Bp) {
+    const int total = nrows * kWidth;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int rr = e & 3, h = (e >> 2) & 1, q = (e >> 3) & 3, kb = (e >> 5) & 7, row = e >> 8;
+        Wp[e] = W[(size_t)row * kWidth + kb * 32 + rr + 8 * q + 4 * h];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 4) Bp[threadIdx.x] = (int)threadIdx.x < nrows ? b[threadIdx.x] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------
+// the MLP kernel
+// ---------------------------------------------------------------------------------------
+#define OCC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+template <int OB>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[OB], const float *__restrict__ Bp, int h) {
+    const f32x4 *B4 = reinterpret_cast<const f32x4 *>(Bp);
+#pragma unroll
+    for (int ob = 0; ob < OB; ob++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 v = B4[(ob * 4 + q) * 2 + h];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) acc[ob][q * 4 + rr] = v[rr];
+        }
+    }
+}
+
+template <int OB>
+__device__ __forceinline__ void load_group(f32x4 (&w)[OB], const f32x4 *__restrict__ W4, int g,
+                                           int lane) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ob++) w[ob] = W4[(g * OB + ob) * 64 + lane];
+}
+
+// One dense layer: acc[ob] += W(group g) x B-operand(k-step t) for all groups.
+// BOP(t) must be an expression with compile-time register indices after unrolling.
+#define OCC_LAYER(GROUPS, OB, W4PTR, ACC, BOP)                                      \
+    {                                                                               \
+        f32x4 wc_[OB], wn_[OB];                                                     \
+        load_group<OB>(wc_, (W4PTR), 0, lane);                                      \
+        _Pragma("unroll") for (int g_ = 0; g_ < (GROUPS); g_++) {                   \
+            if (g_ + 1 < (GROUPS)) load_group<OB>(wn_, (W4PTR), g_ + 1, lane);      \
+            _Pragma("unroll") for (int rr_ = 0; rr_ < 4; rr_++) {                   \
+                const int t_ = g_ * 4 + rr_;                                        \
+                _Pragma("unroll") for (int ob_ = 0; ob_ < (OB); ob_++)              \
+                    ACC[ob_] = OCC_MFMA(wc_[ob_][rr_], BOP(t_), ACC[ob_]);          \
+            }                                                                       \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < (OB); ob_++) wc_[ob_] = wn_[ob_]; \
+        }                                                                           \
+    }
+
+__device__ __forceinline__ void relu_into(f32x16 (&act)[kOB], const f32x16 (&acc)[kOB]) {
+#pragma unroll
+    for (int ob = 0; ob < kOB; ob++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) act[ob][r] = fmaxf(acc[ob][r], 0.0f);
+    }
+}
+
+// dot product of one packed weight row with the lane's 128 activations; the other 128 live
+// in the partner half-wave (lane ^ 32)
+__device__ __forceinline__ float dot_row(const f32x16 (&act)[kOB], const float *__restrict__ Wrow,
+                                         int h) {
+    const f32x4 *W4 = reinterpret_cast<const f32x4 *>(Wrow);
+    float s = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < kOB; kb++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 w = W4[(kb * 4 + q) * 2 + h];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) s = __fmaf_rn(w[rr], act[kb][q * 4 + rr], s);
+        }
+    }
+    return s + __shfl_xor(s, 32);
+}
+
+__global__ __launch_bounds__(256, 1) void canonical_mlp_kernel(const float *__restrict__ mlp_in,
+                                                               int64_t N,
+                                                               const float *__restrict__ pk,
+                                                               float *__restrict__ raw) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile * 32 >= N) return;
+    const int64_t n = tile * 32 + j;
+    const int64_t nsrc = n < N ? n : N - 1;
+
+    // layer-0 B operands: k-step t carries feature t (lanes 0-31) / 34 + t (lanes 32-63)
+    float x[kXRegs];
+    {
+        const float *src = mlp_in + nsrc * kInGeo + h * 34;
+#pragma unroll
+        for (int t = 0; t < 34; t += 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(src + t);
+            x[t] = v.x;
+            x[t + 1] = v.y;
+        }
+        x[34] = 0.0f;
+        x[35] = 0.0f;
+    }
+
+    f32x16 acc[kOB], act[kOB];
+
+    // ---------------- geometry trunk ----------------
+    load_bias<kOB>(acc, pk + Blob::kGeoL0B, h);
+#define BOP_X(t) x[t]
+    OCC_LAYER(kG_L0Geo, kOB, reinterpret_cast<const f32x4 *>(pk + Blob::kGeoL0W), acc, BOP_X)
+    relu_into(act, acc);
+#define BOP_ACT(t) act[(t) >> 4][(t) & 15]
+#pragma unroll 1
+    for (int l = 0; l < 3; l++) {
+        const float *base = pk + Blob::kGeoHW + l * Blob::kHiddenStride;
+        load_bias<kOB>(acc, base + wsz(kG_Hidden, kOB), h);
+        OCC_LAYER(kG_Hidden, kOB, reinterpret_cast<const f32x4 *>(base), acc, BOP_ACT)
+        relu_into(act, acc);
+    }
+    // geometry head: 64 features on MFMA (two blocks, no activation), sigma as a dot row
+    f32x16 geo[2];
+    load_bias<2>(geo, pk + Blob::kGeoHeadB, h);
+    OCC_LAYER(kG_Hidden, 2, reinterpret_cast<const f32x4 *>(pk + Blob::kGeoHeadW), geo, BOP_ACT)
+    const float sigma = dot_row(act, pk + Blob::kSigmaW, h) + pk[Blob::kSigmaB];
+
+    // ---------------- colour trunk ----------------
+    load_bias<kOB>(acc, pk + Blob::kRgbL0B, h);
+#define BOP_RGB0(t) ((t) < 32 ? geo[((t) >> 4) & 1][(t) & 15] : x[((t) - 32) < 0 ? 0 : ((t) - 32)])
+    OCC_LAYER(kG_L0Rgb, kOB, reinterpret_cast<const f32x4 *>(pk + Blob::kRgbL0W), acc, BOP_RGB0)
+    relu_into(act, acc);
+#pragma unroll 1
+    for (int l = 0; l < 3; l++) {
+        const float *base = pk + Blob::kRgbHW + l * Blob::kHiddenStride;
+        load_bias<kOB>(acc, base + wsz(kG_Hidden, kOB), h);
+        OCC_LAYER(kG_Hidden, kOB, reinterpret_cast<const f32x4 *>(base), acc, BOP_ACT)
+        relu_into(act, acc);
+    }
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        rgb[c] = dot_row(act, pk + Blob::kOutW + c * kWidth, h) + pk[Blob::kOutB + c];
+
+    if (h == 0 && n < N) {
+        float *o = raw + n * 5;
+        o[0] = rgb[0];
+        o[1] = rgb[1];
+        o[2] = rgb[2];
+        o[3] = sigma;
+    }
+#undef BOP_X
+#undef BOP_ACT
+#undef BOP_RGB0
+}
+
+}  // namespace occ
+
+OCC_API int64_t occnerf_canonical_mlp_packed_floats(void) { return occ::Blob::kTotal; }
+
+OCC_API int occnerf_canonical_mlp_pack(const float *const *h_W, const float *const *h_b,
+                                       float *packed, void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(h_W && h_b && packed, "canonical_mlp_pack: null argument");
+    for (int i = 0; i < 10; i++) OCC_REQUIRE(h_W[i] && h_b[i], "canonical_mlp_pack: layer %d missing", i);
+    hipStream_t st = as_stream(stream);
+    auto layer = [&](int li, int kind, int in_dim, int out_dim, int groups, int ob, int64_t woff, int64_t boff) {
+        hipLaunchKernelGGL(pack_layer_kernel, dim3(256), dim3(256), 0, st, h_W[li], h_b[li], kind, in_dim,
+                           out_dim, groups, ob, packed + woff, packed + boff);
+    };
+    layer(0, kL0Geo, kInGeo, kWidth, kG_L0Geo, kOB, Blob::kGeoL0W, Blob::kGeoL0B);
+    for (int l = 0; l < 3; l++) {
+        const int64_t base = Blob::kGeoHW + l * Blob::kHiddenStride;
+        layer(1 + l, kHidden, kWidth, kWidth, kG_Hidden, kOB, base, base + wsz(kG_Hidden, kOB));
+    }
+    layer(4, kGeoHead, kWidth, 65, kG_Hidden, 2, Blob::kGeoHeadW, Blob::kGeoHeadB);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(4), dim3(256), 0, st, h_W[4], h_b[4], 1,
+                       packed + Blob::kSigmaW, packed + Blob::kSigmaB);
+    layer(5, kL0Rgb, kInRgb, kWidth, kG_L0Rgb, kOB, Blob::kRgbL0W, Blob::kRgbL0B);
+    for (int l = 0; l < 3; l++) {
+        const int64_t base = Blob::kRgbHW + l * Blob::kHiddenStride;
+        layer(6 + l, kHidden, kWidth, kWidth, kG_Hidden, kOB, base, base + wsz(kG_Hidden, kOB));
+    }
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(4), dim3(256), 0, st, h_W[9], h_b[9], 3,
+                       packed + Blob::kOutW, packed + Blob::kOutB);
+    return check_launch("canonical_mlp_pack");
+}
+
+OCC_API int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *packed, float *raw,
+                                  void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(mlp_in && packed && raw, "canonical_mlp: null argument");
+    if (N <= 0) return 0;
+    const int64_t blocks = (N + 127) / 128;
+    OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp: N too large");
+    hipLaunchKernelGGL(canonical_mlp_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       mlp_in, N, packed, raw);
+    return check_launch("canonical_mlp");
+}

@@ -1,0 +1,255 @@
+// Pose-conditioned non-rigid offset MLP on fp32 MFMA.
+//
+//   emb = Hann-windowed Fourier embedding of xyz, 6 octaves x (sin, cos) x 3 = 36
+//         (embedders/hannw_fourier.py:9-63; the window is all ones at render time)
+//   h   = [cond(69), emb(36)] -> 128 -> 128 -> 128 -> 128 -> [h, emb](164) -> 128 -> 128 -> 3
+//         (non_rigid_motion_mlps/mlp_offset.py:7-62, skip at layer index 4)
+//   xyz += offset                                                    (network.py:225-232)
+//
+// Same register-resident scheme as mlp.hip: one wave = 32 samples, layer outputs in the
+// 32x32 MFMA C/D layout are the next layer's B operands, weights pre-packed in matching k
+// order.  The 69 condition inputs are identical for every sample of a frame, so their
+// contribution to layer 0 is folded into its bias once per call (same fma order as the
+// dense evaluation: bias first, then k = 0..68), which removes 8 832 of the 100 352 MAC.
+//
+// MFMA per wave: 80 + 3*256 + 336 + 256 = 1440 (algorithmic 1424).  Bound: fp32 MFMA.
+#include "common.h"
+
+namespace occ {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kNrW = 128, kNrOB = 4;
+constexpr int kCond = 69, kEmb = 36, kEmbHalf = 18;
+constexpr int kERegs = 20;                       // 18 embedding k-steps + 2 pad
+constexpr int kG_E = kERegs / 4;                 // 5
+constexpr int kG_H = kNrW / 2 / 4;               // 16
+
+constexpr int64_t nr_wsz(int groups) { return (int64_t)groups * kNrOB * 64 * 4; }
+struct NrBlob {
+    static constexpr int64_t kL0W = 0;                                  // embedding part only
+    static constexpr int64_t kL0B = kL0W + nr_wsz(kG_E);               // folded bias (per call)
+    static constexpr int64_t kHW = kL0B + kNrW;                        // layers 1..3
+    static constexpr int64_t kHStride = nr_wsz(kG_H) + kNrW;
+    static constexpr int64_t kSkipW = kHW + 3 * kHStride;              // layer 4: 16 + 5 groups
+    static constexpr int64_t kSkipB = kSkipW + nr_wsz(kG_H + kG_E);
+    static constexpr int64_t kL5W = kSkipB + kNrW;
+    static constexpr int64_t kL5B = kL5W + nr_wsz(kG_H);
+    static constexpr int64_t kOutW = kL5B + kNrW;                      // 3 dot rows
+    static constexpr int64_t kOutB = kOutW + 3 * kNrW;
+    static constexpr int64_t kTotal = kOutB + 4;
+};
+
+enum NrKind { kNrL0 = 0, kNrHidden = 1, kNrSkip = 2 };
+
+__host__ __device__ inline int nr_slot_feature(int kind, int t, int h) {
+    const int blk = t >> 4, r = t & 15;
+    const int cd = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    switch (kind) {
+        case kNrL0: return t < kEmbHalf ? kCond + h * kEmbHalf + t : -1;
+        case kNrHidden: return cd;
+        case kNrSkip:
+            if (t < 64) return cd;
+            return (t - 64) < kEmbHalf ? kNrW + h * kEmbHalf + (t - 64) : -1;
+    }
+    return -1;
+}
+
+__global__ void nr_pack_layer_kernel(const float *__restrict__ W, const float *__restrict__ b,
+                                     int kind, int in_dim, int groups, float *__restrict__ Wp,
+                                     float *__restrict__ Bp) {
+    const int total = groups * kNrOB * 64 * 4;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int rr = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+        const int ob = rest % kNrOB, g = rest / kNrOB;
+        const int col = nr_slot_feature(kind, g * 4 + rr, lane >> 5);
+        Wp[e] = col >= 0 ? W[(size_t)(ob * 32 + (lane & 31)) * in_dim + col] : 0.0f;
+    }
+    if (Bp) {
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kNrW; e += gridDim.x * blockDim.x) {
+            const int rr = e & 3, h = (e >> 2) & 1, q = (e >> 3) & 3, ob = e >> 5;
+            Bp[e] = b[ob * 32 + rr + 8 * q + 4 * h];
+        }
+    }
+}
+
+__global__ void nr_pack_rows_kernel(const float *__restrict__ W, const float *__restrict__ b,
+                                    float *__restrict__ Wp, float *__restrict__ Bp) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 3 * kNrW; e += gridDim.x * blockDim.x) {
+        const int rr = e & 3, h = (e >> 2) & 1, q = (e >> 3) & 3, kb = (e >> 5) & 3, row = e >> 7;
+        Wp[e] = W[(size_t)row * kNrW + kb * 32 + rr + 8 * q + 4 * h];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 4) Bp[threadIdx.x] = threadIdx.x < 3 ? b[threadIdx.x] : 0.0f;
+}
+
+// layer-0 bias with the frame's condition code folded in: b + W[:, :69] cond, fma chain
+// in k order starting from the bias (the order a dense k = 0..104 evaluation would use)
+__global__ void nr_fold_bias_kernel(const float *__restrict__ W0, const float *__restrict__ b0,
+                                    const float *__restrict__ cond, float *__restrict__ Bp) {
+    const int e = threadIdx.x;
+    if (e >= kNrW) return;
+    const int rr = e & 3, h = (e >> 2) & 1, q = (e >> 3) & 3, ob = e >> 5;
+    const int row = ob * 32 + rr + 8 * q + 4 * h;
+    float acc = b0[row];
+    for (int k = 0; k < kCond; k++) acc = __fmaf_rn(W0[(size_t)row * (kCond + kEmb) + k], cond[k], acc);
+    Bp[e] = acc;
+}
+
+#define OCC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void nr_load_bias(f32x16 (&acc)[kNrOB], const float *__restrict__ Bp, int h) {
+    const f32x4 *B4 = reinterpret_cast<const f32x4 *>(Bp);
+#pragma unroll
+    for (int ob = 0; ob < kNrOB; ob++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 v = B4[(ob * 4 + q) * 2 + h];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) acc[ob][q * 4 + rr] = v[rr];
+        }
+    }
+}
+
+#define NR_LAYER(GROUPS, W4PTR, ACC, BOP)                                                     \
+    {                                                                                         \
+        const f32x4 *w4_ = (W4PTR);                                                           \
+        f32x4 wc_[kNrOB], wn_[kNrOB];                                                         \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) wc_[ob_] = w4_[ob_ * 64 + lane]; \
+        _Pragma("unroll") for (int g_ = 0; g_ < (GROUPS); g_++) {                             \
+            if (g_ + 1 < (GROUPS)) {                                                          \
+                _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++)                       \
+                    wn_[ob_] = w4_[((g_ + 1) * kNrOB + ob_) * 64 + lane];                     \
+            }                                                                                 \
+            _Pragma("unroll") for (int rr_ = 0; rr_ < 4; rr_++) {                             \
+                const int t_ = g_ * 4 + rr_;                                                  \
+                _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++)                       \
+                    ACC[ob_] = OCC_MFMA(wc_[ob_][rr_], BOP(t_), ACC[ob_]);                    \
+            }                                                                                 \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) wc_[ob_] = wn_[ob_];      \
+        }                                                                                     \
+    }
+
+struct NrParams {
+    float hann[6];
+};
+
+__global__ __launch_bounds__(256, 2) void nonrigid_kernel(const float *__restrict__ xyz_in, int64_t N,
+                                                          const float *__restrict__ pk, NrParams prm,
+                                                          float *__restrict__ xyz_out) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile * 32 >= N) return;
+    const int64_t n = tile * 32 + j;
+    const int64_t nsrc = n < N ? n : N - 1;
+    const float p[3] = {xyz_in[nsrc * 3], xyz_in[nsrc * 3 + 1], xyz_in[nsrc * 3 + 2]};
+
+    // embedding feature f = octave*6 + {sin: 0..2, cos: 3..5}; this half-wave holds features
+    // h*18 .. h*18+17, i.e. octaves 3h .. 3h+2
+    float e[kERegs];
+#pragma unroll
+    for (int o = 0; o < 3; o++) {
+        const int oct = 3 * h + o;
+        const float freq = (float)(1 << oct);
+        const float wgt = oct == 0 ? prm.hann[0] : oct == 1 ? prm.hann[1] : oct == 2 ? prm.hann[2]
+                        : oct == 3 ? prm.hann[3] : oct == 4 ? prm.hann[4] : prm.hann[5];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float a = __fmul_rn(p[c], freq);
+            e[o * 6 + c] = __fmul_rn(wgt, sinf(a));
+            e[o * 6 + 3 + c] = __fmul_rn(wgt, cosf(a));
+        }
+    }
+    e[18] = 0.0f;
+    e[19] = 0.0f;
+
+    f32x16 acc[kNrOB], act[kNrOB];
+#define BOP_E(t) e[t]
+#define BOP_A(t) act[(t) >> 4][(t) & 15]
+#define BOP_SKIP(t) ((t) < 64 ? act[((t) >> 4) & 3][(t) & 15] : e[((t) - 64) < 0 ? 0 : ((t) - 64)])
+#define NR_RELU()                                                                     \
+    _Pragma("unroll") for (int ob = 0; ob < kNrOB; ob++) {                            \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) act[ob][r] = fmaxf(acc[ob][r], 0.0f); \
+    }
+    nr_load_bias(acc, pk + NrBlob::kL0B, h);
+    NR_LAYER(kG_E, reinterpret_cast<const f32x4 *>(pk + NrBlob::kL0W), acc, BOP_E)
+    NR_RELU()
+#pragma unroll 1
+    for (int l = 0; l < 3; l++) {
+        const float *base = pk + NrBlob::kHW + l * NrBlob::kHStride;
+        nr_load_bias(acc, base + nr_wsz(kG_H), h);
+        NR_LAYER(kG_H, reinterpret_cast<const f32x4 *>(base), acc, BOP_A)
+        NR_RELU()
+    }
+    nr_load_bias(acc, pk + NrBlob::kSkipB, h);
+    NR_LAYER(kG_H + kG_E, reinterpret_cast<const f32x4 *>(pk + NrBlob::kSkipW), acc, BOP_SKIP)
+    NR_RELU()
+    nr_load_bias(acc, pk + NrBlob::kL5B, h);
+    NR_LAYER(kG_H, reinterpret_cast<const f32x4 *>(pk + NrBlob::kL5W), acc, BOP_A)
+    NR_RELU()
+
+    float off[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const f32x4 *W4 = reinterpret_cast<const f32x4 *>(pk + NrBlob::kOutW + c * kNrW);
+        float s = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < kNrOB; kb++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 w = W4[(kb * 4 + q) * 2 + h];
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) s = __fmaf_rn(w[rr], act[kb][q * 4 + rr], s);
+            }
+        }
+        off[c] = s + __shfl_xor(s, 32) + pk[NrBlob::kOutB + c];
+    }
+    if (h == 0 && n < N) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) xyz_out[n * 3 + c] = __fadd_rn(p[c], off[c]);
+    }
+}
+
+}  // namespace occ
+
+OCC_API int64_t occnerf_nonrigid_packed_floats(void) { return occ::NrBlob::kTotal; }
+
+OCC_API int occnerf_nonrigid_pack(const float *const *h_W, const float *const *h_b, float *packed,
+                                  void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(h_W && h_b && packed, "nonrigid_pack: null argument");
+    for (int i = 0; i < 7; i++) OCC_REQUIRE(h_W[i] && h_b[i], "nonrigid_pack: layer %d missing", i);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(nr_pack_layer_kernel, dim3(64), dim3(256), 0, st, h_W[0], h_b[0], (int)kNrL0,
+                       kCond + kEmb, kG_E, packed + NrBlob::kL0W, (float *)nullptr);
+    for (int l = 0; l < 3; l++) {
+        const int64_t base = NrBlob::kHW + l * NrBlob::kHStride;
+        hipLaunchKernelGGL(nr_pack_layer_kernel, dim3(64), dim3(256), 0, st, h_W[1 + l], h_b[1 + l],
+                           (int)kNrHidden, kNrW, kG_H, packed + base, packed + base + nr_wsz(kG_H));
+    }
+    hipLaunchKernelGGL(nr_pack_layer_kernel, dim3(64), dim3(256), 0, st, h_W[4], h_b[4], (int)kNrSkip,
+                       kNrW + kEmb, kG_H + kG_E, packed + NrBlob::kSkipW, packed + NrBlob::kSkipB);
+    hipLaunchKernelGGL(nr_pack_layer_kernel, dim3(64), dim3(256), 0, st, h_W[5], h_b[5], (int)kNrHidden,
+                       kNrW, kG_H, packed + NrBlob::kL5W, packed + NrBlob::kL5B);
+    hipLaunchKernelGGL(nr_pack_rows_kernel, dim3(2), dim3(256), 0, st, h_W[6], h_b[6],
+                       packed + NrBlob::kOutW, packed + NrBlob::kOutB);
+    return check_launch("nonrigid_pack");
+}
+
+OCC_API int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
+                             const float *W0, const float *b0, float *packed, float *xyz_out,
+                             void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && xyz_out, "nonrigid: null argument");
+    if (N <= 0) return 0;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(nr_fold_bias_kernel, dim3(1), dim3(128), 0, st, W0, b0, cond, packed + NrBlob::kL0B);
+    NrParams prm;
+    for (int i = 0; i < 6; i++) prm.hann[i] = h_hann[i];
+    const int64_t blocks = (N + 127) / 128;
+    OCC_REQUIRE(blocks < (1ll << 31), "nonrigid: N too large");
+    hipLaunchKernelGGL(nonrigid_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N, packed, prm,
+                       xyz_out);
+    return check_launch("nonrigid");
+}

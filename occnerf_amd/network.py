@@ -1,0 +1,264 @@
+"""`Network`: the renderer module, drop-in for core/nets/occnerf/network.py:38-623.
+
+Same constructor (no arguments, reads the global cfg), same `generate_neural_points`,
+`deploy_mlps_to_secondary_gpus`, `point_cloud`, `forward(**data, iter_val=...)` keyword
+surface and output dict, and the same state_dict key names/shapes,
+so a reference checkpoint loads with strict=True.  What differs is how a frame is rendered:
+
+  reference                                         here
+  ------------------------------------------------  -----------------------------------------
+  ray chunks of 32768 x sample chunks of 300000,    one pass over all samples of the frame
+  ~150 torch kernels + pykeops per chunk            (HBM holds them), six HIP kernels
+  per-point SDF block recomputed in every chunk     hoisted: once per frame (network.py:263-284)
+  fourier embedding of xyz computed, never used     skipped (network.py:287; occnerf_mlp.py:180)
+  nn.DataParallel over samples                      one process per GPU, rays sharded
+                                                    (occnerf_amd/parallel.py)
+
+Per-frame small stuff (pose decoder, motion bases, motion-weight volume) stays torch
+(occnerf_amd/modules.py); everything per sample goes through the C ABI (occnerf_amd/ops.py).
+There is no CPU path: forward() raises if the parameters are not on a GPU.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import geometry, ops
+from .canonical_mlp import CanonicalMLP
+from .config import get_cfg
+from .modules import (BodyPoseRefiner, MotionBasisComputer, MotionWeightVolumeDecoder,
+                      NonRigidMotionMLP, hann_window_weights)
+
+
+class _Replica(nn.Module):
+    """Keeps the `.module.` infix nn.DataParallel puts into the reference's state_dict keys
+    (cnl_mlp.module.*, non_rigid_mlp.module.*) without any of its behaviour."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+def _load_smpl(cfg):
+    """The SMPL body: the licensed model when present, else the synthetic stand-in."""
+    choice = cfg.get('smpl_model', 'auto')
+    model_dir = './third_parties/smpl/models' if choice in ('auto', 'synthetic') else choice
+    pkl = os.path.join(model_dir, 'basicModel_neutral_lbs_10_207_0_v1.0.0.pkl')
+    if choice != 'synthetic' and os.path.exists(pkl):
+        from third_parties.smpl.smpl_numpy import SMPL   # the user's reference checkout
+        return SMPL(sex='neutral', model_dir=model_dir)
+    from .synth import SyntheticSMPL
+    return SyntheticSMPL()
+
+
+class Network(nn.Module):
+    def __init__(self, avg_betas=None):
+        super().__init__()
+        cfg = get_cfg()
+        self.cfg = cfg
+        self.motion_basis_computer = MotionBasisComputer(total_bones=cfg.total_bones)
+        self.mweight_vol_decoder = MotionWeightVolumeDecoder(
+            embedding_size=cfg.mweight_volume.embedding_size,
+            volume_size=cfg.mweight_volume.volume_size, total_bones=cfg.total_bones)
+        nr = cfg.non_rigid_motion_mlp
+        self.non_rigid_mlp = _Replica(NonRigidMotionMLP(
+            pos_embed_size=nr.multires * 6, condition_code_size=nr.condition_code_size,
+            mlp_width=nr.mlp_width, mlp_depth=nr.mlp_depth, skips=nr.skips))
+        self.pose_decoder = BodyPoseRefiner(
+            embedding_size=cfg.pose_decoder.embedding_size, mlp_width=cfg.pose_decoder.mlp_width,
+            mlp_depth=cfg.pose_decoder.mlp_depth, total_bones=cfg.total_bones)
+        self._ctx = None           # device-side constants of the sample pipeline
+        self._packed = None        # MFMA-ordered MLP weights (eval: cached)
+
+    # ------------------------------------------------------------------ model set-up
+    def generate_neural_points(self, avg_betas):
+        """network.py:90-146: body points, normals, bound, 3 FPS scales, canonical MLP."""
+        cfg = self.cfg
+        self.smpl = _load_smpl(cfg)
+        betas = np.zeros(10) if avg_betas is None else np.asarray(avg_betas)
+        verts, joints = self.smpl(np.zeros(72,), betas)
+        try:
+            import trimesh
+            normals = np.asarray(trimesh.Trimesh(vertices=verts, faces=self.smpl.faces, process=False,
+                                                 maintain_order=True).vertex_normals)
+        except ImportError:
+            normals = geometry.vertex_normals(verts, self.smpl.faces)
+        min_xyz = np.min(joints, axis=0) - cfg.bbox_offset
+        max_xyz = np.max(joints, axis=0) + cfg.bbox_offset
+        self.bound = np.max(np.abs(list(min_xyz) + list(max_xyz)))
+        self.detailed_bound = torch.tensor(np.array([list(min_xyz), list(max_xyz)]))
+
+        self.point_base = nn.Parameter(torch.tensor(verts).float(), requires_grad=False)
+        self.point_dist = nn.Parameter(torch.zeros(verts.shape[0], 1).float(), requires_grad=True)
+        self.point_dist.data.uniform_(-1e-4, 1e-4)
+        self.point_counter = nn.Parameter(torch.ones(verts.shape[0]), requires_grad=False)
+        self.point_norms = torch.tensor(normals)            # float64, like trimesh's
+
+        self.fps_index, ratio = [], 1.0
+        for _ in range(3):                                   # 1/4, 1/16, 1/64 (network.py:113-118)
+            ratio /= 4
+            self.fps_index.append(torch.from_numpy(geometry.farthest_point_sampling(verts, ratio)))
+
+        self.cnl_mlp = _Replica(CanonicalMLP(
+            mlp_depth=cfg.canonical_mlp.mlp_depth, mlp_width=cfg.canonical_mlp.mlp_width,
+            input_ch=63, skips=[], bound=self.bound, detailed_bound=self.detailed_bound))
+        self._ctx = self._packed = None
+
+    def deploy_mlps_to_secondary_gpus(self):
+        return self          # single device per process; rays are sharded across processes
+
+    @property
+    def point_cloud(self):
+        return self.point_base + self.point_dist
+
+    def invalidate_cache(self):
+        """Call after changing weights in place while in eval mode (load_state_dict does)."""
+        self._ctx = self._packed = None
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.invalidate_cache()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate_cache()
+        return out
+
+    # ------------------------------------------------------------------ device constants
+    def _context(self):
+        """Padded multi-scale point array, index map, float64 normals: constant per model."""
+        dev = self.point_base.device
+        if self._ctx is not None and self._ctx['device'] == dev:
+            return self._ctx
+        base = self.point_base.detach()
+        P = base.shape[0]
+        sets = [torch.arange(P)] + [f.long() for f in self.fps_index]
+        rows, imap, begin = [], [], [0]
+        for idx in sets:
+            pts = base[idx.to(dev)]
+            pad = (-pts.shape[0]) % 4                       # +inf rows: never selected
+            rows.append(torch.cat([pts, torch.full((pad, 3), float('inf'), device=dev)]))
+            imap.append(torch.cat([idx, torch.zeros(pad, dtype=idx.dtype)]))
+            begin.append(begin[-1] + pts.shape[0] + pad)
+        pts4 = torch.cat(rows)
+        pts4 = torch.cat([pts4, torch.zeros(pts4.shape[0], 1, device=dev)], dim=1).contiguous()
+        # scale s may reuse the search radius found at scale s+1 when it contains it
+        as_sets = [set(s.tolist()) for s in sets]
+        seed = [int(l + 1 < len(sets) and as_sets[l + 1] <= as_sets[l]) for l in range(len(sets))]
+        normals = self.point_norms.to(dev).double().contiguous()
+        self._ctx = {
+            'device': dev, 'points': pts4, 'index_map': torch.cat(imap).int().to(dev),
+            'scale_begin': begin, 'seed': seed, 'normals': normals,
+            'unit': ops.unit_normals(normals),
+            'bound32': float(np.float32(self.bound)),
+            'two_bound32': float(np.float32(2 * np.float64(self.bound))),
+        }
+        return self._ctx
+
+    def _packed_weights(self):
+        if self._packed is not None and not self.training:
+            return self._packed
+        cm, nr = self.cnl_mlp.module, self.non_rigid_mlp.module
+        nr_lin = [m for m in nr.block_mlps if isinstance(m, nn.Linear)]
+        self._packed = {
+            'cnl': ops.canonical_mlp_pack(*cm.linear_params()),
+            'nr': ops.nonrigid_pack([m.weight.detach() for m in nr_lin],
+                                    [m.bias.detach() for m in nr_lin]),
+            'nr_w0': nr_lin[0].weight.detach(), 'nr_b0': nr_lin[0].bias.detach(),
+        }
+        return self._packed
+
+    def _point_stage(self, ctx):
+        """network.py:263-284 + occnerf_mlp.py:171-175, once per frame."""
+        enc = self.cnl_mlp.module.encoder
+        pc = self.point_cloud.detach().float().contiguous()
+        base = self.point_base.detach()
+        kidx = ops.knn_small(pc, base, 3)
+        knn_base, sdf = ops.point_sdf(pc, base, ctx['normals'], ctx['unit'], kidx)
+        table = ops.point_table(knn_base, sdf, pc, ctx['bound32'], ctx['two_bound32'],
+                                enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale,
+                                enc.base_resolution)
+        return table
+
+    # ------------------------------------------------------------------ sample pipeline
+    def _render_rays(self, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann,
+                     table, t_rand=None):
+        cfg, ctx = self.cfg, self._context()
+        S = int(cfg.N_samples)
+        enc = self.cnl_mlp.module.encoder
+        t_vals = torch.linspace(0., 1., steps=S, device=rays8.device)
+        z, xyz, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale,
+                                          t_rand=t_rand)
+        pk = self._packed_weights()
+        if not cfg.ignore_non_rigid_motions:
+            xyz = ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
+        knn = ops.msknn(xyz, ctx['points'], ctx['index_map'], ctx['scale_begin'], ctx['seed'])
+        mlp_in, raw, _ = ops.sample_features(
+            xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
+            self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
+            enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution)
+        del knn
+        ops.canonical_mlp(mlp_in, pk['cnl'], raw)
+        del mlp_in
+        rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
+        return rgb, acc, depth
+
+    @staticmethod
+    def _host3(v):
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        return np.asarray(v, dtype=np.float32).reshape(3)
+
+    def forward(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None,
+                near=None, far=None, iter_val=1e7, **kwargs):
+        cfg = self.cfg
+        dev = self.point_base.device
+        if dev.type != 'cuda':
+            raise RuntimeError('occnerf_amd.Network renders on a GPU only; move the module with '
+                               '.cuda() first (the reference has no CPU path either)')
+        dst_Rs, dst_Ts = dst_Rs[None], dst_Ts[None]
+        dst_posevec, cnl_gtfms = dst_posevec[None], cnl_gtfms[None]
+        motion_weights_priors = motion_weights_priors[None]
+
+        with torch.no_grad():
+            # ---- per frame, torch (network.py:557-596) ----
+            if iter_val >= cfg.pose_decoder.get('kick_in_iter', 0):
+                refined = self.pose_decoder(dst_posevec)['Rs']
+                tb = cfg.total_bones - 1
+                no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3),
+                                       refined.reshape(-1, 3, 3)).reshape(-1, tb, 3, 3)
+                dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
+            nr = cfg.non_rigid_motion_mlp
+            hann = hann_window_weights(nr.multires, iter_val, nr.kick_in_iter, nr.full_band_iter)
+            cond = dst_posevec if iter_val >= nr.kick_in_iter else torch.zeros_like(dst_posevec)
+            Rs, Ts = self.motion_basis_computer(dst_Rs, dst_Ts, cnl_gtfms)
+            vol = self.mweight_vol_decoder(motion_weights_priors=motion_weights_priors)[0]
+
+            rays_o, rays_d = rays
+            rays8 = torch.cat([rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float(),
+                               near.reshape(-1, 1).float(), far.reshape(-1, 1).float()], -1).contiguous()
+            bbox_min = self._host3(kwargs['cnl_bbox_min_xyz'])
+            bbox_scale = self._host3(kwargs['cnl_bbox_scale_xyz'])
+            bgcolor = self._host3(kwargs['bgcolor'])
+            table = self._point_stage(self._context())
+
+            # ---- per sample, HIP; all rays of the frame in as few passes as memory allows ----
+            S = int(cfg.N_samples)
+            rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 26)) // S)
+            outs = []
+            for i in range(0, rays8.shape[0], rays_per_pass):
+                outs.append(self._render_rays(
+                    rays8[i:i + rays_per_pass], Rs[0].contiguous(), Ts[0].contiguous(),
+                    vol.contiguous(), bbox_min, bbox_scale, bgcolor,
+                    cond.reshape(-1).float().contiguous(), hann.tolist(), table))
+            rgb, acc, depth = (torch.cat(t, 0) if len(outs) > 1 else outs[0][j]
+                               for j, t in enumerate(zip(*outs)))
+        shape = list(rays_d.shape[:-1])
+        return {'rgb': rgb.reshape(shape + [3]), 'alpha': acc.reshape(shape),
+                'depth': depth.reshape(shape),
+                'comp_loss': torch.zeros(1, device=dev)}

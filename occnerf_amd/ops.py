@@ -1,0 +1,257 @@
+"""Torch-facing wrappers of the C ABI (include/occnerf_hip.h).
+
+Each function validates its tensors (GPU, contiguous, dtype -- the reference's
+CHECK_CUDA / CHECK_CONTIGUOUS / CHECK_IS_* of gridencoder.cu:15-18, raised as
+RuntimeError), allocates outputs with torch, and launches on torch's current stream of
+the tensors' device.  PyTorch is plumbing here: memory, streams, device guard.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_f32p = C.POINTER(C.c_float)
+
+
+def _chk(t, dtype, name):
+    if not torch.is_tensor(t):
+        raise RuntimeError(f'{name} must be a tensor')
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a CUDA(HIP) tensor; there is no CPU path')
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name} must be a contiguous tensor')
+    if t.dtype != dtype:
+        raise RuntimeError(f'{name} must be {dtype}, got {t.dtype}')
+    return t.data_ptr()
+
+
+def _opt(t, dtype, name):
+    return None if t is None else _chk(t, dtype, name)
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _host_f32(vals, n):
+    a = np.ascontiguousarray(np.asarray(vals, dtype=np.float32).ravel())
+    assert a.size == n, (a.size, n)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _host_i32(vals):
+    a = np.ascontiguousarray(np.asarray(vals, dtype=np.int32).ravel())
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _ptr_table(tensors, name):
+    ptrs = [_chk(t, torch.float32, f'{name}[{i}]') for i, t in enumerate(tensors)]
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    return arr
+
+
+# ------------------------------------------------------------------ grid encoder (section 1)
+def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H, dy_dx=None,
+                        gridtype=0, align_corners=False, interp=0):
+    """Same positional signature as the reference's `_gridencoder.grid_encode_forward`
+    (bindings.cpp:6); writes `outputs[L,B,C]` (and `dy_dx`) in place."""
+    with torch.cuda.device(inputs.device):
+        rc = _lib.lib().occnerf_grid_encode_forward(
+            _chk(inputs, torch.float32, 'inputs'), _chk(embeddings, torch.float32, 'embeddings'),
+            _chk(offsets, torch.int32, 'offsets'), _chk(outputs, torch.float32, 'outputs'),
+            int(B), int(D), int(Cc), int(L), float(S), int(H), _opt(dy_dx, torch.float32, 'dy_dx'),
+            int(gridtype), int(bool(align_corners)), int(interp), _stream(inputs))
+    _lib.check(rc, 'grid_encode_forward')
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H,
+                         dy_dx=None, grad_inputs=None, gridtype=0, align_corners=False, interp=0):
+    """`_gridencoder.grid_encode_backward` (bindings.cpp:7)."""
+    with torch.cuda.device(inputs.device):
+        rc = _lib.lib().occnerf_grid_encode_backward(
+            _chk(grad, torch.float32, 'grad'), _chk(inputs, torch.float32, 'inputs'),
+            _chk(embeddings, torch.float32, 'embeddings'), _chk(offsets, torch.int32, 'offsets'),
+            _chk(grad_embeddings, torch.float32, 'grad_embeddings'), int(B), int(D), int(Cc), int(L),
+            float(S), int(H), _opt(dy_dx, torch.float32, 'dy_dx'),
+            _opt(grad_inputs, torch.float32, 'grad_inputs'), int(gridtype),
+            int(bool(align_corners)), int(interp), _stream(inputs))
+    _lib.check(rc, 'grid_encode_backward')
+
+
+def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, Cc, L, S, H, gridtype=0,
+                         align_corners=False):
+    """`_gridencoder.grad_total_variation` (bindings.cpp:8): exported, not implemented."""
+    rc = _lib.lib().occnerf_grad_total_variation(None, None, None, None, float(weight), int(B), int(D),
+                                                 int(Cc), int(L), float(S), int(H), int(gridtype),
+                                                 int(bool(align_corners)), None)
+    _lib.check(rc, 'grad_total_variation')
+
+
+# ------------------------------------------------------------------ sample pipeline (section 2)
+def sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale, t_rand=None, want_pts=False):
+    """rays8[n,8] -> z_vals[n,S], x_skel[n*S,3], mask[n*S] (, pts[n*S,3])."""
+    n = rays8.shape[0]
+    dev = rays8.device
+    z = torch.empty(n, S, device=dev, dtype=torch.float32)
+    xs = torch.empty(n * S, 3, device=dev, dtype=torch.float32)
+    mk = torch.empty(n * S, device=dev, dtype=torch.float32)
+    pts = torch.empty(n * S, 3, device=dev, dtype=torch.float32) if want_pts else None
+    _kmin, pmin = _host_f32(bbox_min, 3)
+    _ksc, psc = _host_f32(bbox_scale, 3)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().occnerf_sample_warp(
+            _chk(rays8, torch.float32, 'rays'), n, int(S), _chk(t_vals, torch.float32, 't_vals'),
+            _opt(t_rand, torch.float32, 't_rand'), _chk(Rs, torch.float32, 'Rs'),
+            _chk(Ts, torch.float32, 'Ts'), _chk(vol, torch.float32, 'vol'), int(Rs.shape[0]),
+            int(vol.shape[-1]), pmin, psc, z.data_ptr(), None if pts is None else pts.data_ptr(),
+            xs.data_ptr(), mk.data_ptr(), _stream(rays8))
+    _lib.check(rc, 'sample_warp')
+    return z, xs, mk, pts
+
+
+def nonrigid_pack(weights, biases):
+    dev = weights[0].device
+    n = _lib.lib().occnerf_nonrigid_packed_floats()
+    packed = torch.zeros(n, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().occnerf_nonrigid_pack(_ptr_table(weights, 'W'), _ptr_table(biases, 'b'),
+                                              packed.data_ptr(), _stream(packed))
+    _lib.check(rc, 'nonrigid_pack')
+    return packed
+
+
+def nonrigid(xyz, cond, hann, W0, b0, packed, out=None):
+    out = torch.empty_like(xyz) if out is None else out
+    _kh, ph = _host_f32(hann, 6)
+    with torch.cuda.device(xyz.device):
+        rc = _lib.lib().occnerf_nonrigid(
+            _chk(xyz, torch.float32, 'xyz'), xyz.shape[0], _chk(cond, torch.float32, 'cond'), ph,
+            _chk(W0, torch.float32, 'W0'), _chk(b0, torch.float32, 'b0'),
+            _chk(packed, torch.float32, 'packed'), _chk(out, torch.float32, 'xyz_out'), _stream(xyz))
+    _lib.check(rc, 'nonrigid')
+    return out
+
+
+def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
+    N = xyz.shape[0]
+    nscale = len(scale_begin) - 1
+    out = torch.empty(N, nscale, 10, device=xyz.device, dtype=torch.int32)
+    _kb, pb = _host_i32(scale_begin)
+    _ks, ps = _host_i32(seed_from_coarser)
+    with torch.cuda.device(xyz.device):
+        rc = _lib.lib().occnerf_msknn(_chk(xyz, torch.float32, 'xyz'), N,
+                                      _chk(points, torch.float32, 'points'),
+                                      _chk(index_map, torch.int32, 'index_map'), pb, ps, nscale,
+                                      out.data_ptr(), _stream(xyz))
+    _lib.check(rc, 'msknn')
+    return out
+
+
+def knn_small(q, s, k):
+    out = torch.empty(q.shape[0], k, device=q.device, dtype=torch.int32)
+    with torch.cuda.device(q.device):
+        rc = _lib.lib().occnerf_knn_small(_chk(q, torch.float32, 'q'), q.shape[0],
+                                          _chk(s, torch.float32, 's'), s.shape[0], int(k),
+                                          out.data_ptr(), _stream(q))
+    _lib.check(rc, 'knn_small')
+    return out
+
+
+def unit_normals(normals):
+    out = torch.empty_like(normals)
+    with torch.cuda.device(normals.device):
+        rc = _lib.lib().occnerf_unit_normals(_chk(normals, torch.float64, 'normals'), normals.shape[0],
+                                             out.data_ptr(), _stream(normals))
+    _lib.check(rc, 'unit_normals')
+    return out
+
+
+def point_sdf(point_cloud, point_base, normals, unit, kidx):
+    P = point_cloud.shape[0]
+    kb = torch.empty(P, 3, device=point_cloud.device, dtype=torch.float64)
+    dist = torch.empty(P, device=point_cloud.device, dtype=torch.float32)
+    with torch.cuda.device(point_cloud.device):
+        rc = _lib.lib().occnerf_point_sdf(
+            _chk(point_cloud, torch.float32, 'point_cloud'), _chk(point_base, torch.float32, 'point_base'),
+            _chk(normals, torch.float64, 'normals'), _chk(unit, torch.float64, 'unit_normals'),
+            _chk(kidx, torch.int32, 'kidx'), P, kb.data_ptr(), dist.data_ptr(), _stream(point_cloud))
+    _lib.check(rc, 'point_sdf')
+    return kb, dist
+
+
+def point_table(knn_base, sdf, learnable, bound32, two_bound32, embeddings, offsets, S, H):
+    P = knn_base.shape[0]
+    table = torch.empty(P, 36, device=knn_base.device, dtype=torch.float32)
+    with torch.cuda.device(knn_base.device):
+        rc = _lib.lib().occnerf_point_table(
+            _chk(knn_base, torch.float64, 'knn_base'), _chk(sdf, torch.float32, 'point_sdf'),
+            _chk(learnable, torch.float32, 'learnable'), P, float(bound32), float(two_bound32),
+            _chk(embeddings, torch.float32, 'embeddings'), _chk(offsets, torch.int32, 'offsets'),
+            int(offsets.shape[0] - 1), float(S), int(H), table.data_ptr(), _stream(knn_base))
+    _lib.check(rc, 'point_table')
+    return table
+
+
+def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bound32, two_bound32,
+                    embeddings, offsets, S, H, raw=None, want_enc_in=False, geo_idxs=None,
+                    att_in=None):
+    N = xyz.shape[0]
+    dev = xyz.device
+    mlp_in = torch.empty(N, 68, device=dev, dtype=torch.float32)
+    raw = torch.empty(N, 5, device=dev, dtype=torch.float32) if raw is None else raw
+    enc_in = torch.empty(N, 4, device=dev, dtype=torch.float32) if want_enc_in else None
+    with torch.cuda.device(dev):
+        rc = _lib.lib().occnerf_sample_features(
+            _chk(xyz, torch.float32, 'xyz'), N, _chk(knn_idxs, torch.int32, 'knn_idxs'),
+            int(knn_idxs.shape[1]), _chk(point_base, torch.float32, 'point_base'),
+            _chk(normals, torch.float64, 'normals'), _chk(unit, torch.float64, 'unit_normals'),
+            _opt(counter, torch.float32, 'counter'), _chk(table, torch.float32, 'table'),
+            float(bound32), float(two_bound32), _chk(embeddings, torch.float32, 'embeddings'),
+            _chk(offsets, torch.int32, 'offsets'), int(offsets.shape[0] - 1), float(S), int(H),
+            _opt(geo_idxs, torch.int32, 'geo_idxs'), _opt(att_in, torch.float32, 'att_in'),
+            mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
+            None if enc_in is None else enc_in.data_ptr(), _stream(xyz))
+    _lib.check(rc, 'sample_features')
+    return mlp_in, raw, enc_in
+
+
+def canonical_mlp_pack(weights, biases):
+    """weights/biases: the 10 Linear layers in module order (see the header)."""
+    dev = weights[0].device
+    n = _lib.lib().occnerf_canonical_mlp_packed_floats()
+    packed = torch.zeros(n, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().occnerf_canonical_mlp_pack(_ptr_table(weights, 'W'), _ptr_table(biases, 'b'),
+                                                   packed.data_ptr(), _stream(packed))
+    _lib.check(rc, 'canonical_mlp_pack')
+    return packed
+
+
+def canonical_mlp(mlp_in, packed, raw):
+    with torch.cuda.device(mlp_in.device):
+        rc = _lib.lib().occnerf_canonical_mlp(_chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0],
+                                              _chk(packed, torch.float32, 'packed'),
+                                              _chk(raw, torch.float32, 'raw'), _stream(mlp_in))
+    _lib.check(rc, 'canonical_mlp')
+    return raw
+
+
+def composite(raw, mask, z_vals, rays8, bgcolor, want_weights=False, want_term=False):
+    n, S = z_vals.shape
+    dev = raw.device
+    rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    acc = torch.empty(n, device=dev, dtype=torch.float32)
+    dep = torch.empty(n, device=dev, dtype=torch.float32)
+    w = torch.empty(n, S, device=dev, dtype=torch.float32) if want_weights else None
+    tp = torch.empty(n, device=dev, dtype=torch.int32) if want_term else None
+    _kbg, pbg = _host_f32(bgcolor, 3)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().occnerf_composite(
+            _chk(raw, torch.float32, 'raw'), _chk(mask, torch.float32, 'mask'),
+            _chk(z_vals, torch.float32, 'z_vals'), _chk(rays8, torch.float32, 'rays'), pbg, n, int(S),
+            rgb.data_ptr(), acc.data_ptr(), dep.data_ptr(), None if w is None else w.data_ptr(),
+            None if tp is None else tp.data_ptr(), _stream(raw))
+    _lib.check(rc, 'composite')
+    return rgb, acc, dep, w, tp

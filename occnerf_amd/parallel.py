@@ -1,0 +1,64 @@
+"""Multi-GPU: rays shard, one process per GPU, one gather per frame.
+
+Rays are independent (the only cross-sample dependency is the scan inside one ray), so the
+`ray_mask`-compacted ray list is cut into `world_size` contiguous blocks; every rank holds the
+full (61 MiB) model, renders its block with no data-path collective, and the `[R/N, 5]`
+(rgb, alpha, depth) blocks are gathered on rank 0 over RCCL/xGMI (<= 5.2 MB per 512^2 frame:
+latency-bound, one collective).  This replaces the reference's nn.DataParallel over *samples*
+with its per-call weight broadcast (network.py:68-72,142-146), it does not mirror it.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rays, world_size):
+    """[lo, hi) of every rank's contiguous block; sizes differ by at most one."""
+    base, rem = divmod(int(n_rays), int(world_size))
+    bounds, lo = [], 0
+    for r in range(world_size):
+        hi = lo + base + (1 if r < rem else 0)
+        bounds.append((lo, hi))
+        lo = hi
+    return bounds
+
+
+def shard_frame(data, rank, world_size):
+    """Slice the per-ray entries of a frame dict (rays[2,R,3], near/far[R,1]) for `rank`."""
+    R = data['rays'].shape[1]
+    lo, hi = shard_bounds(R, world_size)[rank]
+    out = dict(data)
+    out['rays'] = data['rays'][:, lo:hi]
+    out['near'], out['far'] = data['near'][lo:hi], data['far'][lo:hi]
+    return out, (lo, hi)
+
+
+def gather_rays(block, n_rays, dst=0, group=None):
+    """Gather per-rank `[r_i, C]` blocks into `[n_rays, C]` on rank `dst` (None elsewhere).
+    Blocks are padded to the largest shard so one fixed-size gather suffices."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return block
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bounds = shard_bounds(n_rays, world)
+    width = max(hi - lo for lo, hi in bounds)
+    padded = block.new_zeros((width,) + tuple(block.shape[1:]))
+    padded[:block.shape[0]] = block
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, bounds)], 0)
+
+
+def render_frame_sharded(net, data, iter_val=1e7, group=None):
+    """Render this rank's block of `data` and gather (rgb, alpha, depth) on rank 0.
+    Returns the full-frame dict on rank 0 and None on the other ranks."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    R = data['rays'].shape[1]
+    local, _ = shard_frame(data, rank, world)
+    out = net(**local, iter_val=iter_val)
+    packed = torch.cat([out['rgb'], out['alpha'][:, None], out['depth'][:, None]], dim=1)
+    full = gather_rays(packed, R, dst=0, group=group)
+    if full is None:
+        return None
+    return {'rgb': full[:, :3], 'alpha': full[:, 3], 'depth': full[:, 4]}

@@ -1,0 +1,109 @@
+"""CPU: host-side logic -- config, synthetic inputs, checkpoint surface, ray sharding (gloo)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_merge_and_cli(tmp_path):
+    from occnerf_amd.config import make_cfg
+    y = tmp_path / 'exp.yaml'
+    y.write_text('N_samples: 64\ncanonical_mlp:\n  mlp_width: 256\nfreeview:\n  frame_idx: 128\n')
+    cfg, args = make_cfg(['--cfg', str(y), '--type', 'freeview', 'chunk', '1024', 'bgcolor', '[255.,255.,255.]'])
+    assert args.type == 'freeview' and cfg.N_samples == 64 and cfg.chunk == 1024
+    assert cfg.freeview.frame_idx == 128 and cfg.bgcolor == [255., 255., 255.]
+    assert cfg.logdir == os.path.join('experiments', 'occnerf', 'zju_mocap', 'p387', 'occnerf')
+    assert cfg.non_rigid_motion_mlp.kick_in_iter == 100000 and cfg.pose_decoder.kick_in_iter == 2000000
+
+
+def test_synthetic_body_and_frame():
+    from occnerf_amd import geometry, synth
+    smpl = synth.SyntheticSMPL()
+    v, j = smpl(np.zeros(72), np.zeros(10))
+    assert v.shape == (6890, 3) and j.shape == (24, 3) and smpl.faces.max() == 6889
+    n = geometry.vertex_normals(v, smpl.faces)
+    assert n.dtype == np.float64 and np.allclose(np.linalg.norm(n, axis=1), 1)
+    fps = geometry.farthest_point_sampling(v, 1 / 16)
+    assert len(fps) == 431 and len(set(fps.tolist())) == 431 and fps[0] == 0
+    f = synth.make_frame(64)
+    R = f['rays'].shape[1]
+    assert f['ray_mask'].sum() == R and f['near'].shape == (R, 1) and np.all(f['far'] > f['near'])
+    assert f['motion_weights_priors'].shape == (25, 32, 32, 32)
+    assert np.allclose(f['motion_weights_priors'].sum(0), 1, atol=1e-5)
+
+
+def test_network_state_dict_surface_on_cpu():
+    """Key names/shapes are the reference's: the seeded checkpoint loads strict."""
+    from tests.gpu_util import build_network
+    net, ctx = build_network(0, False, S=32, device='cpu')
+    assert list(net.state_dict().keys()) == list(ctx['sd'].keys())
+    assert net.cnl_mlp.module.encoder.embeddings.shape == (7755336, 2)
+    assert hasattr(net, 'mweight_vol_decoder') and net.point_cloud.shape == (6890, 3)
+    frame = {'rays': torch.zeros(2, 4, 3)}
+    with pytest.raises(RuntimeError, match='GPU'):       # no silent CPU fallback
+        net(rays=frame['rays'], dst_Rs=torch.zeros(24, 3, 3), dst_Ts=torch.zeros(24, 3),
+            cnl_gtfms=torch.zeros(24, 4, 4), motion_weights_priors=torch.ones(25, 32, 32, 32),
+            dst_posevec=torch.zeros(69), near=torch.zeros(4, 1), far=torch.ones(4, 1))
+
+
+def test_shard_bounds():
+    from occnerf_amd.parallel import shard_bounds
+    for n, w in [(262144, 8), (183784, 8), (7, 8), (0, 2), (1000, 3)]:
+        b = shard_bounds(n, w)
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, n_rays, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from occnerf_amd.parallel import render_frame_sharded, shard_bounds
+
+    class FakeNet:                                       # renders rgb = f(ray) per ray, no coupling
+        def __call__(self, rays, near, far, iter_val=0, **_):
+            o = rays[0]
+            return {'rgb': o * 2.0, 'alpha': near[:, 0] + 1.0, 'depth': far[:, 0] * 3.0}
+    g = torch.Generator().manual_seed(0)
+    data = {'rays': torch.rand(2, n_rays, 3, generator=g), 'near': torch.rand(n_rays, 1, generator=g),
+            'far': torch.rand(n_rays, 1, generator=g)}
+    out = render_frame_sharded(FakeNet(), data)
+    if rank == 0:
+        ok = (torch.equal(out['rgb'], data['rays'][0] * 2.0) and torch.equal(out['alpha'], data['near'][:, 0] + 1.0)
+              and torch.equal(out['depth'], data['far'][:, 0] * 3.0))
+        q.put(bool(ok))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_rays', [1001, 64])
+def test_ray_sharding_gather_gloo_world2(n_rays):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n_rays, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=120) is True
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
