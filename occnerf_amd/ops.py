@@ -27,6 +27,18 @@ def _chk(t, dtype, name):
     return t.data_ptr()
 
 
+def _guard_dev(dev):
+    if torch.device(dev).type != 'cuda':
+        raise RuntimeError(f'tensors are on {dev}: this path runs on a GPU only, there is no CPU path')
+    return torch.cuda.device(dev)
+
+
+def _guard(t):
+    if not torch.is_tensor(t):
+        raise RuntimeError('expected a tensor')
+    return _guard_dev(t.device)
+
+
 def _opt(t, dtype, name):
     return None if t is None else _chk(t, dtype, name)
 
@@ -57,7 +69,7 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H,
                         gridtype=0, align_corners=False, interp=0):
     """Same positional signature as the reference's `_gridencoder.grid_encode_forward`
     (bindings.cpp:6); writes `outputs[L,B,C]` (and `dy_dx`) in place."""
-    with torch.cuda.device(inputs.device):
+    with _guard(inputs):
         rc = _lib.lib().occnerf_grid_encode_forward(
             _chk(inputs, torch.float32, 'inputs'), _chk(embeddings, torch.float32, 'embeddings'),
             _chk(offsets, torch.int32, 'offsets'), _chk(outputs, torch.float32, 'outputs'),
@@ -69,7 +81,7 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H,
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H,
                          dy_dx=None, grad_inputs=None, gridtype=0, align_corners=False, interp=0):
     """`_gridencoder.grid_encode_backward` (bindings.cpp:7)."""
-    with torch.cuda.device(inputs.device):
+    with _guard(inputs):
         rc = _lib.lib().occnerf_grid_encode_backward(
             _chk(grad, torch.float32, 'grad'), _chk(inputs, torch.float32, 'inputs'),
             _chk(embeddings, torch.float32, 'embeddings'), _chk(offsets, torch.int32, 'offsets'),
@@ -100,7 +112,7 @@ def sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale, t_rand=None
     pts = torch.empty(n * S, 3, device=dev, dtype=torch.float32) if want_pts else None
     _kmin, pmin = _host_f32(bbox_min, 3)
     _ksc, psc = _host_f32(bbox_scale, 3)
-    with torch.cuda.device(dev):
+    with _guard_dev(dev):
         rc = _lib.lib().occnerf_sample_warp(
             _chk(rays8, torch.float32, 'rays'), n, int(S), _chk(t_vals, torch.float32, 't_vals'),
             _opt(t_rand, torch.float32, 't_rand'), _chk(Rs, torch.float32, 'Rs'),
@@ -115,7 +127,7 @@ def nonrigid_pack(weights, biases):
     dev = weights[0].device
     n = _lib.lib().occnerf_nonrigid_packed_floats()
     packed = torch.zeros(n, device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev):
+    with _guard_dev(dev):
         rc = _lib.lib().occnerf_nonrigid_pack(_ptr_table(weights, 'W'), _ptr_table(biases, 'b'),
                                               packed.data_ptr(), _stream(packed))
     _lib.check(rc, 'nonrigid_pack')
@@ -125,7 +137,7 @@ def nonrigid_pack(weights, biases):
 def nonrigid(xyz, cond, hann, W0, b0, packed, out=None):
     out = torch.empty_like(xyz) if out is None else out
     _kh, ph = _host_f32(hann, 6)
-    with torch.cuda.device(xyz.device):
+    with _guard(xyz):
         rc = _lib.lib().occnerf_nonrigid(
             _chk(xyz, torch.float32, 'xyz'), xyz.shape[0], _chk(cond, torch.float32, 'cond'), ph,
             _chk(W0, torch.float32, 'W0'), _chk(b0, torch.float32, 'b0'),
@@ -140,7 +152,7 @@ def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
     out = torch.empty(N, nscale, 10, device=xyz.device, dtype=torch.int32)
     _kb, pb = _host_i32(scale_begin)
     _ks, ps = _host_i32(seed_from_coarser)
-    with torch.cuda.device(xyz.device):
+    with _guard(xyz):
         rc = _lib.lib().occnerf_msknn(_chk(xyz, torch.float32, 'xyz'), N,
                                       _chk(points, torch.float32, 'points'),
                                       _chk(index_map, torch.int32, 'index_map'), pb, ps, nscale,
@@ -151,7 +163,7 @@ def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
 
 def knn_small(q, s, k):
     out = torch.empty(q.shape[0], k, device=q.device, dtype=torch.int32)
-    with torch.cuda.device(q.device):
+    with _guard(q):
         rc = _lib.lib().occnerf_knn_small(_chk(q, torch.float32, 'q'), q.shape[0],
                                           _chk(s, torch.float32, 's'), s.shape[0], int(k),
                                           out.data_ptr(), _stream(q))
@@ -161,7 +173,7 @@ def knn_small(q, s, k):
 
 def unit_normals(normals):
     out = torch.empty_like(normals)
-    with torch.cuda.device(normals.device):
+    with _guard(normals):
         rc = _lib.lib().occnerf_unit_normals(_chk(normals, torch.float64, 'normals'), normals.shape[0],
                                              out.data_ptr(), _stream(normals))
     _lib.check(rc, 'unit_normals')
@@ -172,7 +184,7 @@ def point_sdf(point_cloud, point_base, normals, unit, kidx):
     P = point_cloud.shape[0]
     kb = torch.empty(P, 3, device=point_cloud.device, dtype=torch.float64)
     dist = torch.empty(P, device=point_cloud.device, dtype=torch.float32)
-    with torch.cuda.device(point_cloud.device):
+    with _guard(point_cloud):
         rc = _lib.lib().occnerf_point_sdf(
             _chk(point_cloud, torch.float32, 'point_cloud'), _chk(point_base, torch.float32, 'point_base'),
             _chk(normals, torch.float64, 'normals'), _chk(unit, torch.float64, 'unit_normals'),
@@ -184,7 +196,7 @@ def point_sdf(point_cloud, point_base, normals, unit, kidx):
 def point_table(knn_base, sdf, learnable, bound32, two_bound32, embeddings, offsets, S, H):
     P = knn_base.shape[0]
     table = torch.empty(P, 36, device=knn_base.device, dtype=torch.float32)
-    with torch.cuda.device(knn_base.device):
+    with _guard(knn_base):
         rc = _lib.lib().occnerf_point_table(
             _chk(knn_base, torch.float64, 'knn_base'), _chk(sdf, torch.float32, 'point_sdf'),
             _chk(learnable, torch.float32, 'learnable'), P, float(bound32), float(two_bound32),
@@ -202,7 +214,7 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
     mlp_in = torch.empty(N, 68, device=dev, dtype=torch.float32)
     raw = torch.empty(N, 5, device=dev, dtype=torch.float32) if raw is None else raw
     enc_in = torch.empty(N, 4, device=dev, dtype=torch.float32) if want_enc_in else None
-    with torch.cuda.device(dev):
+    with _guard_dev(dev):
         rc = _lib.lib().occnerf_sample_features(
             _chk(xyz, torch.float32, 'xyz'), N, _chk(knn_idxs, torch.int32, 'knn_idxs'),
             int(knn_idxs.shape[1]), _chk(point_base, torch.float32, 'point_base'),
@@ -222,7 +234,7 @@ def canonical_mlp_pack(weights, biases):
     dev = weights[0].device
     n = _lib.lib().occnerf_canonical_mlp_packed_floats()
     packed = torch.zeros(n, device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev):
+    with _guard_dev(dev):
         rc = _lib.lib().occnerf_canonical_mlp_pack(_ptr_table(weights, 'W'), _ptr_table(biases, 'b'),
                                                    packed.data_ptr(), _stream(packed))
     _lib.check(rc, 'canonical_mlp_pack')
@@ -230,7 +242,7 @@ def canonical_mlp_pack(weights, biases):
 
 
 def canonical_mlp(mlp_in, packed, raw):
-    with torch.cuda.device(mlp_in.device):
+    with _guard(mlp_in):
         rc = _lib.lib().occnerf_canonical_mlp(_chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0],
                                               _chk(packed, torch.float32, 'packed'),
                                               _chk(raw, torch.float32, 'raw'), _stream(mlp_in))
@@ -247,7 +259,7 @@ def composite(raw, mask, z_vals, rays8, bgcolor, want_weights=False, want_term=F
     w = torch.empty(n, S, device=dev, dtype=torch.float32) if want_weights else None
     tp = torch.empty(n, device=dev, dtype=torch.int32) if want_term else None
     _kbg, pbg = _host_f32(bgcolor, 3)
-    with torch.cuda.device(dev):
+    with _guard_dev(dev):
         rc = _lib.lib().occnerf_composite(
             _chk(raw, torch.float32, 'raw'), _chk(mask, torch.float32, 'mask'),
             _chk(z_vals, torch.float32, 'z_vals'), _chk(rays8, torch.float32, 'rays'), pbg, n, int(S),
