@@ -119,6 +119,7 @@ OCC_API int occnerf_composite(const float *raw, const float *mask, const float *
                               float *rgb, float *acc, float *depth, float *weights, int32_t *term,
                               void *stream) {
     using namespace occ;
+    if (n <= 0) return 0;
     OCC_REQUIRE(raw && mask && z_vals && rays && h_bgcolor && rgb && acc && depth, "composite: null argument");
     OCC_REQUIRE(S >= 1, "composite: S=%d", S);
     if (n <= 0) return 0;

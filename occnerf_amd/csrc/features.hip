@@ -308,6 +308,7 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                                     const float *att_in, float *mlp_in, float *raw, float *enc_in,
                                     void *stream) {
     using namespace occ;
+    if (N <= 0) return 0;
     OCC_REQUIRE(xyz && knn_idxs && point_base && normals && unit_normals && (counter || att_in) && table &&
                     embeddings && offsets && mlp_in && raw, "sample_features: null argument");
     OCC_REQUIRE(nscale >= 1 && nscale <= 4, "sample_features: nscale=%d unsupported", nscale);

@@ -243,6 +243,7 @@ OCC_API int occnerf_grid_encode_forward(const float *inputs, const float *embedd
                                         float *dy_dx, uint32_t gridtype, int align_corners,
                                         uint32_t interp, void *stream) {
     using namespace occ;
+    if (B == 0) return 0;
     OCC_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null tensor");
     OCC_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward: L=%u unsupported (1..%d)", L, kMaxLevels);
     if (B == 0) return 0;
@@ -266,6 +267,7 @@ OCC_API int occnerf_grid_encode_backward(const float *grad, const float *inputs,
                                          uint32_t interp, void *stream) {
     using namespace occ;
     (void)embeddings;
+    if (B == 0) return 0;
     OCC_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null tensor");
     OCC_REQUIRE((dy_dx == nullptr) == (grad_inputs == nullptr),
                 "grid_encode_backward: dy_dx and grad_inputs must be given together");

@@ -191,6 +191,7 @@ OCC_API int occnerf_msknn(const float *xyz, int64_t N, const float *points,
                           const int32_t *h_seed_from_coarser, int32_t nscale, int32_t *knn_idxs,
                           void *stream) {
     using namespace occ;
+    if (N <= 0) return 0;
     OCC_REQUIRE(xyz && points && index_map && h_scale_begin && knn_idxs, "msknn: null argument");
     OCC_REQUIRE(nscale >= 1 && nscale <= 4, "msknn: nscale=%d unsupported (1..4)", nscale);
     if (N <= 0) return 0;
@@ -215,6 +216,7 @@ OCC_API int occnerf_msknn(const float *xyz, int64_t N, const float *points,
 OCC_API int occnerf_knn_small(const float *q, int32_t nq, const float *s, int32_t ns, int32_t k,
                               int32_t *idx, void *stream) {
     using namespace occ;
+    if (nq <= 0) return 0;
     OCC_REQUIRE(q && s && idx, "knn_small: null argument");
     OCC_REQUIRE(ns >= k, "knn_small: fewer support points (%d) than k (%d)", ns, k);
     if (nq <= 0) return 0;

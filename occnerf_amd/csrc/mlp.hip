@@ -299,6 +299,7 @@ OCC_API int occnerf_canonical_mlp_pack(const float *const *h_W, const float *con
 OCC_API int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *packed, float *raw,
                                   void *stream) {
     using namespace occ;
+    if (N <= 0) return 0;
     OCC_REQUIRE(mlp_in && packed && raw, "canonical_mlp: null argument");
     if (N <= 0) return 0;
     const int64_t blocks = (N + 127) / 128;

@@ -241,6 +241,7 @@ OCC_API int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, 
                              const float *W0, const float *b0, float *packed, float *xyz_out,
                              void *stream) {
     using namespace occ;
+    if (N <= 0) return 0;
     OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && xyz_out, "nonrigid: null argument");
     if (N <= 0) return 0;
     hipStream_t st = as_stream(stream);

@@ -126,6 +126,7 @@ OCC_API int occnerf_sample_warp(const float *rays, int64_t n, int32_t S, const f
                                 const float *h_bbox_scale, float *z_vals, float *pts, float *x_skel,
                                 float *mask, void *stream) {
     using namespace occ;
+    if (n <= 0) return 0;
     OCC_REQUIRE(rays && t_vals && Rs && Ts && vol && h_bbox_min && h_bbox_scale && z_vals && x_skel && mask,
                 "sample_warp: null argument");
     OCC_REQUIRE(S >= 1 && nb >= 1 && nb <= kMaxBones && G >= 2, "sample_warp: bad sizes S=%d nb=%d G=%d", S, nb, G);
