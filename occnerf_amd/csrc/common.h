@@ -111,9 +111,11 @@ __device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const f
     return r;
 }
 
-// torch's fp32 2-norm of a 3-vector: sqrt(fma(z,z,fma(y,y,x*x))) (oracle: oc_norm3)
+// torch's fp32 2-norm of a 3-vector: sqrt(fma(z,z,fma(y,y,x*x))) (oracle: oc_norm3).
+// sqrtf is the correctly rounded one on this toolchain; __fsqrt_rn is NOT (measured on
+// gfx950 / ROCm 7.2: 16 % of inputs off by one ulp), despite its name.
 __device__ __forceinline__ float norm3(float x, float y, float z) {
-    return __fsqrt_rn(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+    return sqrtf(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
 }
 
 }  // namespace occ

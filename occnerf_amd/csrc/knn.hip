@@ -64,7 +64,7 @@ __device__ __forceinline__ float filter_bound(float s) { return s * s * 1.000000
 
 __device__ __forceinline__ void consider(KBest &b, float &thr, float d2, int row) {
     if (d2 < thr) {
-        const float s = __fsqrt_rn(d2);
+        const float s = sqrtf(d2);
         if (s < b.s[kK - 1]) {
             kbest_insert(b, s, row);
             thr = fminf(thr, filter_bound(b.s[kK - 1]));
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void knn_small_kernel(const float *__restrict_
     }
     for (int j = 0; j < ns; j++) {
         const float dx = qx - s[j * 3], dy = qy - s[j * 3 + 1], dz = qz - s[j * 3 + 2];
-        const float d = __fsqrt_rn(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx))));
+        const float d = sqrtf(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx))));
         if (d < bs[K - 1]) {
             bs[K - 1] = d;
             bi[K - 1] = j;
