@@ -63,7 +63,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--cpu-rays', type=int, default=768, help='rays in the CPU baseline sample')
+    ap.add_argument('--cpu-rays', type=int, default=4096, help='rays in the CPU baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

@@ -220,7 +220,8 @@ OCC_API int occnerf_knn_small(const float *q, int32_t nq, const float *s, int32_
     OCC_REQUIRE(q && s && idx, "knn_small: null argument");
     OCC_REQUIRE(ns >= k, "knn_small: fewer support points (%d) than k (%d)", ns, k);
     if (nq <= 0) return 0;
-    const dim3 grid((nq + 255) / 256), block(256);
+    // a few thousand queries at most: 64-thread blocks spread them over more CUs
+    const dim3 grid((nq + 63) / 64), block(64);
     hipStream_t st = as_stream(stream);
     switch (k) {
         case 1: hipLaunchKernelGGL((knn_small_kernel<1>), grid, block, 0, st, q, nq, s, ns, idx); break;
