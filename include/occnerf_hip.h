@@ -168,6 +168,18 @@ int occnerf_canonical_mlp_pack(const float *const *h_W, const float *const *h_b,
 int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *packed, float *raw,
                           void *stream);
 
+/* The same two trunks on the bf16 matrix pipe with split operands ("bf16x3"): every fp32
+ * weight and activation is carried as hi + lo bf16 (16 significand bits) and each product is
+ * Wh*xh + Wh*xl + Wl*xh accumulated in fp32 -- 5.3x the fp32-MFMA rate.  Outputs differ from
+ * the fp32 kernel by <= ~1e-5 on the raw logits (DESIGN.md section 3.1 has the measured
+ * pixel-level effect, two orders inside the 1e-4 gate).  packed = the fp32 blob above (biases,
+ * sigma and colour-head rows stay fp32); packed_bf16 = occnerf_canonical_mlp_packed_bf16_bytes()
+ * bytes written by occnerf_canonical_mlp_pack_bf16 from the same 10 weight pointers. */
+int64_t occnerf_canonical_mlp_packed_bf16_bytes(void);
+int occnerf_canonical_mlp_pack_bf16(const float *const *h_W, void *packed_bf16, void *stream);
+int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const float *packed,
+                                 const void *packed_bf16, float *raw, void *stream);
+
 /* Alpha compositing, network.py:320-348.  raw[n,S,5], mask[n*S], z_vals[n,S],
  * rays[n,8] (direction at floats 3..5), h_bgcolor[3] host, 0..255.
  * Outputs rgb[n,3], acc[n], depth[n]; weights[n,S] and term[n] (argmax alpha) optional. */

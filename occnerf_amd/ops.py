@@ -250,6 +250,28 @@ def canonical_mlp(mlp_in, packed, raw):
     return raw
 
 
+def canonical_mlp_pack_bf16(weights):
+    """hi/lo bf16 split of the 10 weight matrices in bf16-MFMA operand order."""
+    dev = weights[0].device
+    n = _lib.lib().occnerf_canonical_mlp_packed_bf16_bytes()
+    packed = torch.zeros(n // 2, device=dev, dtype=torch.bfloat16)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_canonical_mlp_pack_bf16(_ptr_table(weights, 'W'), packed.data_ptr(),
+                                                        _stream(packed))
+    _lib.check(rc, 'canonical_mlp_pack_bf16')
+    return packed
+
+
+def canonical_mlp_bf16x3(mlp_in, packed, packed_bf16, raw):
+    with _guard(mlp_in):
+        rc = _lib.lib().occnerf_canonical_mlp_bf16x3(
+            _chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0], _chk(packed, torch.float32, 'packed'),
+            _chk(packed_bf16, torch.bfloat16, 'packed_bf16'), _chk(raw, torch.float32, 'raw'),
+            _stream(mlp_in))
+    _lib.check(rc, 'canonical_mlp_bf16x3')
+    return raw
+
+
 def composite(raw, mask, z_vals, rays8, bgcolor, want_weights=False, want_term=False):
     n, S = z_vals.shape
     dev = raw.device

@@ -277,6 +277,23 @@ def test_sample_features_and_mlp(case, ops):
     assert np.abs(raw2.cpu().numpy()[:, :4] - ref).max() <= (5e-5 if amp else 1e-6)
 
 
+def test_canonical_mlp_bf16x3(case, ops):
+    """Split-bf16 MFMA variant: hi/lo operands, three products, fp32 accumulation.  Bound from
+    the operand split (2^-17 relative per product): raw logits within 3e-5 (random init) of
+    float64; the pixel-level effect is checked end to end (test_network_end_to_end_bf16x3)."""
+    g, ctx, o = case
+    Wg, Bg, Wc, Bc = util.canonical_mlp_params(ctx['sd'])
+    W = [T(w) for w in Wg + Wc]
+    B = [T(b) for b in Bg + Bc]
+    packed, packed_h = ops.canonical_mlp_pack(W, B), ops.canonical_mlp_pack_bf16(W)
+    raw = torch.zeros(o['mlp_in'].shape[0], 5, device=DEV)
+    ops.canonical_mlp_bf16x3(T(o['mlp_in']), packed, packed_h, raw)
+    from tests.test_oracle_golden import _mlp_f64
+    ref = _mlp_f64(o['mlp_in'], Wg, Bg, Wc, Bc)
+    err = np.abs(raw.cpu().numpy()[:, :4] - ref).max()
+    assert err <= (2e-4 if g['meta.amplify'] else 3e-5), err
+
+
 def test_canonical_mlp_module_gathered_interface(case, ops):
     """CanonicalMLP.forward with the reference's keyword surface (gathered neighbours)."""
     g, ctx, o = case
