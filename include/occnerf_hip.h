@@ -174,11 +174,15 @@ int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *packed, f
  * the fp32 kernel by <= ~1e-5 on the raw logits (DESIGN.md section 3.1 has the measured
  * pixel-level effect, two orders inside the 1e-4 gate).  packed = the fp32 blob above (biases,
  * sigma and colour-head rows stay fp32); packed_bf16 = occnerf_canonical_mlp_packed_bf16_bytes()
- * bytes written by occnerf_canonical_mlp_pack_bf16 from the same 10 weight pointers. */
+ * bytes (zero-initialised by the caller: the tail is read-ahead padding) written by
+ * occnerf_canonical_mlp_pack_bf16 from the same 10 weight pointers.
+ * variant 0: weights staged through LDS by LDS-DMA (the fast one); 1: every wave loads its
+ * own operands from L2 (kept for A/B measurements). */
 int64_t occnerf_canonical_mlp_packed_bf16_bytes(void);
 int occnerf_canonical_mlp_pack_bf16(const float *const *h_W, void *packed_bf16, void *stream);
 int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const float *packed,
-                                 const void *packed_bf16, float *raw, void *stream);
+                                 const void *packed_bf16, float *raw, int32_t variant,
+                                 void *stream);
 
 /* Alpha compositing, network.py:320-348.  raw[n,S,5], mask[n*S], z_vals[n,S],
  * rays[n,8] (direction at floats 3..5), h_bgcolor[3] host, 0..255.

@@ -477,6 +477,243 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_kernel(
 #undef BOPS_RGB0
 }
 
+
+// ---------------------------------------------------------------------------------------
+// bf16x3, LDS-staged weights.  The direct-load kernel above makes each of the 4 waves of a
+// workgroup pull the whole 1.8 MB weight stream through L1 itself (85 B/clk/CU against a
+// 64 B/clk L1): it runs at ~40 % of the bf16 pipe.  Here the stream is cut into 16 KiB chunks
+// (one 16-wide k-step x {hi,lo} x 8 output blocks) that the workgroup fetches ONCE with
+// LDS-DMA (global_load_lds_dwordx4, 4 x 1 KiB per wave per chunk) into a 4-slot ring and all
+// four waves read with ds_read_b128.  One raw s_barrier per chunk; the DMA of chunks g+1..g+3
+// stays in flight across it behind a counted s_waitcnt vmcnt(8) (hipcc would drain to
+// vmcnt(0) before the first ds_read if the DMA were a builtin it can see, so the DMA is inline
+// asm and the wait is placed by hand).  Biases and the VALU head rows are copied to LDS once.
+// ---------------------------------------------------------------------------------------
+constexpr int kRingSlots = 4;
+constexpr int kChunkUnits = 1024;                                  // 16-byte units per chunk
+constexpr int kChunksTotal = kS_L0Geo + 3 * kS_Hidden + kS_Hidden / 4 + kS_L0Rgb + 3 * kS_Hidden;
+static_assert(BlobH::kTotal == (int64_t)kChunksTotal * kChunkUnits, "bf16 blob is the chunk stream");
+constexpr int kTailChunks = kRingSlots - 1;                        // zero chunks the prefetch may touch
+
+// fp32 side data in LDS (floats): biases in accumulator order + the dot-row weights
+struct Aux {
+    static constexpr int kGeoL0B = 0;
+    static constexpr int kGeoHB = 256;          // 3 x 256
+    static constexpr int kGeoHeadB = 1024;      // 64
+    static constexpr int kSigma = 1088;         // 256 weights + bias (+3 pad)
+    static constexpr int kRgbL0B = 1348;
+    static constexpr int kRgbHB = 1604;         // 3 x 256
+    static constexpr int kOut = 2372;           // 3 x 256 weights + 3 biases (+1 pad)
+    static constexpr int kTotal = 3144;
+};
+
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;      // M0 carries the wave-uniform LDS destination; lane i lands at +16 i
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int OB>
+__device__ __forceinline__ void lds_bias(f32x16 (&acc)[OB], const float *aux, int h) {
+    const f32x4 *B4 = reinterpret_cast<const f32x4 *>(aux);
+#pragma unroll
+    for (int ob = 0; ob < OB; ob++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 v = B4[(ob * 4 + q) * 2 + h];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) acc[ob][q * 4 + rr] = v[rr];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
+    const float *__restrict__ mlp_in, int64_t N, const float *__restrict__ pk,
+    const bf16x8 *__restrict__ pkh, float *__restrict__ raw) {
+    // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read)
+    __shared__ __attribute__((aligned(16))) bf16x8 smem[kRingSlots * kChunkUnits + Aux::kTotal / 4];
+    bf16x8 *ring = smem;
+    float *aux = reinterpret_cast<float *>(smem + kRingSlots * kChunkUnits);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t n = tile * 32 + j;
+    const int64_t nsrc = n < N ? n : N - 1;      // whole workgroup stays alive for the barriers
+
+    // ---- side data -> LDS, inputs -> registers (ordinary loads, before any DMA is in flight) ----
+    auto copy = [&](int dst, int64_t src, int count) {
+        for (int i = threadIdx.x; i < count; i += 256) aux[dst + i] = pk[src + i];
+    };
+    copy(Aux::kGeoL0B, Blob::kGeoL0B, 256);
+    for (int l = 0; l < 3; l++) copy(Aux::kGeoHB + l * 256, Blob::kGeoHW + l * Blob::kHiddenStride + wsz(kG_Hidden, kOB), 256);
+    copy(Aux::kGeoHeadB, Blob::kGeoHeadB, 64);
+    copy(Aux::kSigma, Blob::kSigmaW, 260);
+    copy(Aux::kRgbL0B, Blob::kRgbL0B, 256);
+    for (int l = 0; l < 3; l++) copy(Aux::kRgbHB + l * 256, Blob::kRgbHW + l * Blob::kHiddenStride + wsz(kG_Hidden, kOB), 256);
+    copy(Aux::kOut, Blob::kOutW, 772);
+
+    SplitB bx[kS_L0Geo];
+    {
+        const float *src = mlp_in + nsrc * kInGeo + h * 34;
+#pragma unroll
+        for (int s = 0; s < kS_L0Geo; s++) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (s * 8 + i) < 34 ? src[s * 8 + i] : 0.0f;
+            bx[s] = split8(v);
+        }
+    }
+    __syncthreads();
+
+    // ---- weight stream: chunk g lives in ring slot g & 3 ----
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) bf16x8 *)ring;
+    auto issue = [&](int g) {      // this wave's quarter of chunk g: 4 x 1 KiB
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const int frag = wave * 4 + f;
+            glds16(pkh + (size_t)g * kChunkUnits + frag * 64 + lane,
+                   ring_lds + (unsigned)(((g & (kRingSlots - 1)) * kChunkUnits + frag * 64) * 16));
+        }
+    };
+    int g = 0;                     // next chunk to consume
+    issue(0);
+    issue(1);
+    issue(2);
+
+    // wait for chunk g (own quarter), rendezvous, refill the slot freed by chunk g-1
+#define OCC_CHUNK_ENTER()                                              \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   \
+    __builtin_amdgcn_s_barrier();                                      \
+    issue(g + 3);                                                      \
+    const bf16x8 *slot_ = ring + (g & (kRingSlots - 1)) * kChunkUnits; \
+    g++;
+
+    // one 16-wide k-step per chunk, 8 output blocks
+#define OCC_LAYER_LDS8(STEPS, ACC, BOPS)                                                   \
+    _Pragma("unroll") for (int s_ = 0; s_ < (STEPS); s_++) {                               \
+        OCC_CHUNK_ENTER()                                                                  \
+        bf16x8 ah_[kOB], al_[kOB];                                                         \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ah_[ob_] = slot_[ob_ * 64 + lane];         \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) al_[ob_] = slot_[(kOB + ob_) * 64 + lane]; \
+        const SplitB &b_ = BOPS(s_);                                                       \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = OCC_MFMA_BF16(ah_[ob_], b_.hi, ACC[ob_]); \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = OCC_MFMA_BF16(ah_[ob_], b_.lo, ACC[ob_]); \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = OCC_MFMA_BF16(al_[ob_], b_.hi, ACC[ob_]); \
+    }
+
+    f32x16 acc[kOB];
+    SplitB bact[2 * kOB];
+
+    // ---------------- geometry trunk ----------------
+    lds_bias<kOB>(acc, aux + Aux::kGeoL0B, h);
+#define BOPS_X(s) bx[s]
+    OCC_LAYER_LDS8(kS_L0Geo, acc, BOPS_X)
+    relu_split(bact, acc);
+#define BOPS_ACT(s) bact[s]
+#pragma unroll 1
+    for (int l = 0; l < 3; l++) {
+        lds_bias<kOB>(acc, aux + Aux::kGeoHB + l * 256, h);
+        OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
+        if (l < 2) relu_split(bact, acc);
+    }
+    float sigma;
+    {
+        const f32x4 *W4 = reinterpret_cast<const f32x4 *>(aux + Aux::kSigma);
+        float sacc = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < kOB; kb++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 w = W4[(kb * 4 + q) * 2 + h];
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) sacc = __fmaf_rn(w[rr], fmaxf(acc[kb][q * 4 + rr], 0.0f), sacc);
+            }
+        }
+        sigma = sacc + __shfl_xor(sacc, 32) + aux[Aux::kSigma + 256];
+    }
+    relu_split(bact, acc);
+    // geometry head: 2 output blocks; a chunk carries 4 k-steps [step][hi|lo][ob][lane]
+    f32x16 geo[2];
+    lds_bias<2>(geo, aux + Aux::kGeoHeadB, h);
+#pragma unroll
+    for (int c = 0; c < kS_Hidden / 4; c++) {
+        OCC_CHUNK_ENTER()
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const SplitB &b = bact[c * 4 + q];
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) {
+                ah[ob] = slot_[((q * 2 + 0) * 2 + ob) * 64 + lane];
+                al[ob] = slot_[((q * 2 + 1) * 2 + ob) * 64 + lane];
+            }
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) geo[ob] = OCC_MFMA_BF16(ah[ob], b.hi, geo[ob]);
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) geo[ob] = OCC_MFMA_BF16(ah[ob], b.lo, geo[ob]);
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) geo[ob] = OCC_MFMA_BF16(al[ob], b.hi, geo[ob]);
+        }
+    }
+    SplitB bgeo[4];
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = geo[b][sub * 8 + i];
+            bgeo[b * 2 + sub] = split8(v);
+        }
+    }
+
+    // ---------------- colour trunk ----------------
+    lds_bias<kOB>(acc, aux + Aux::kRgbL0B, h);
+#define BOPS_RGB0(s) ((s) < 4 ? bgeo[(s) & 3] : bx[((s) - 4) < 0 ? 0 : ((s) - 4)])
+    OCC_LAYER_LDS8(kS_L0Rgb, acc, BOPS_RGB0)
+    relu_split(bact, acc);
+#pragma unroll 1
+    for (int l = 0; l < 3; l++) {
+        lds_bias<kOB>(acc, aux + Aux::kRgbHB + l * 256, h);
+        OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
+        if (l < 2) relu_split(bact, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the 3 tail chunks: nobody reads them
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const f32x4 *W4 = reinterpret_cast<const f32x4 *>(aux + Aux::kOut + c * kWidth);
+        float sacc = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < kOB; kb++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 w = W4[(kb * 4 + q) * 2 + h];
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) sacc = __fmaf_rn(w[rr], fmaxf(acc[kb][q * 4 + rr], 0.0f), sacc);
+            }
+        }
+        rgb[c] = sacc + __shfl_xor(sacc, 32) + aux[Aux::kOut + 3 * kWidth + c];
+    }
+    if (h == 0 && n < N) {
+        float *o = raw + n * 5;
+        o[0] = rgb[0];
+        o[1] = rgb[1];
+        o[2] = rgb[2];
+        o[3] = sigma;
+    }
+#undef BOPS_X
+#undef BOPS_ACT
+#undef BOPS_RGB0
+#undef OCC_LAYER_LDS8
+#undef OCC_CHUNK_ENTER
+}
+
 }  // namespace occ
 
 OCC_API int64_t occnerf_canonical_mlp_packed_floats(void) { return occ::Blob::kTotal; }
@@ -509,7 +746,9 @@ OCC_API int occnerf_canonical_mlp_pack(const float *const *h_W, const float *con
     return check_launch("canonical_mlp_pack");
 }
 
-OCC_API int64_t occnerf_canonical_mlp_packed_bf16_bytes(void) { return occ::BlobH::kTotal * 16; }
+OCC_API int64_t occnerf_canonical_mlp_packed_bf16_bytes(void) {
+    return (occ::BlobH::kTotal + (int64_t)occ::kTailChunks * occ::kChunkUnits) * 16;   // + zero tail chunks
+}
 
 OCC_API int occnerf_canonical_mlp_pack_bf16(const float *const *h_W, void *packed_bf16, void *stream) {
     using namespace occ;
@@ -530,14 +769,20 @@ OCC_API int occnerf_canonical_mlp_pack_bf16(const float *const *h_W, void *packe
 }
 
 OCC_API int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const float *packed,
-                                         const void *packed_bf16, float *raw, void *stream) {
+                                         const void *packed_bf16, float *raw, int32_t variant,
+                                         void *stream) {
     using namespace occ;
     if (N <= 0) return 0;
     OCC_REQUIRE(mlp_in && packed && packed_bf16 && raw, "canonical_mlp_bf16x3: null argument");
     const int64_t blocks = (N + 127) / 128;
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_bf16x3: N too large");
-    hipLaunchKernelGGL(canonical_mlp_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                       mlp_in, N, packed, reinterpret_cast<const bf16x8 *>(packed_bf16), raw);
+    const bf16x8 *pkh = reinterpret_cast<const bf16x8 *>(packed_bf16);
+    if (variant == 0)
+        hipLaunchKernelGGL(canonical_mlp_bf16x3_lds_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                           as_stream(stream), mlp_in, N, packed, pkh, raw);
+    else
+        hipLaunchKernelGGL(canonical_mlp_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                           as_stream(stream), mlp_in, N, packed, pkh, raw);
     return check_launch("canonical_mlp_bf16x3");
 }
 

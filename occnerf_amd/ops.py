@@ -262,12 +262,12 @@ def canonical_mlp_pack_bf16(weights):
     return packed
 
 
-def canonical_mlp_bf16x3(mlp_in, packed, packed_bf16, raw):
+def canonical_mlp_bf16x3(mlp_in, packed, packed_bf16, raw, variant=0):
     with _guard(mlp_in):
         rc = _lib.lib().occnerf_canonical_mlp_bf16x3(
             _chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0], _chk(packed, torch.float32, 'packed'),
             _chk(packed_bf16, torch.bfloat16, 'packed_bf16'), _chk(raw, torch.float32, 'raw'),
-            _stream(mlp_in))
+            int(variant), _stream(mlp_in))
     _lib.check(rc, 'canonical_mlp_bf16x3')
     return raw
 

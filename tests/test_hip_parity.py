@@ -286,12 +286,16 @@ def test_canonical_mlp_bf16x3(case, ops):
     W = [T(w) for w in Wg + Wc]
     B = [T(b) for b in Bg + Bc]
     packed, packed_h = ops.canonical_mlp_pack(W, B), ops.canonical_mlp_pack_bf16(W)
-    raw = torch.zeros(o['mlp_in'].shape[0], 5, device=DEV)
-    ops.canonical_mlp_bf16x3(T(o['mlp_in']), packed, packed_h, raw)
     from tests.test_oracle_golden import _mlp_f64
     ref = _mlp_f64(o['mlp_in'], Wg, Bg, Wc, Bc)
-    err = np.abs(raw.cpu().numpy()[:, :4] - ref).max()
-    assert err <= (2e-4 if g['meta.amplify'] else 3e-5), err
+    outs = []
+    for variant in (0, 1):                       # LDS-staged and direct-load weight streams
+        raw = torch.zeros(o['mlp_in'].shape[0], 5, device=DEV)
+        ops.canonical_mlp_bf16x3(T(o['mlp_in']), packed, packed_h, raw, variant=variant)
+        err = np.abs(raw.cpu().numpy()[:, :4] - ref).max()
+        assert err <= (2e-4 if g['meta.amplify'] else 3e-5), (variant, err)
+        outs.append(raw.cpu().numpy())
+    same(outs[0], outs[1], 'bf16x3 LDS vs direct')   # same products, same order
 
 
 def test_canonical_mlp_module_gathered_interface(case, ops):

@@ -39,11 +39,12 @@ def main():
     raw = torch.zeros(N, 5, device=dev)
     t32 = timeit(lambda: ops.canonical_mlp(mlp_in, packed, raw))
     r32 = raw.clone()
-    tb = timeit(lambda: ops.canonical_mlp_bf16x3(mlp_in, packed, packed_h, raw))
     flop = 923136.0 * N
-    print(f'canonical_mlp fp32   : {t32:8.2f} ms  {flop / t32 / 1e9:8.1f} TFLOP/s')
-    print(f'canonical_mlp bf16x3 : {tb:8.2f} ms  {flop / tb / 1e9:8.1f} TFLOP/s (algorithmic)  '
-          f'max|diff vs fp32| = {float((raw[:, :4] - r32[:, :4]).abs().max()):.3e}')
+    print(f'canonical_mlp fp32          : {t32:8.2f} ms  {flop / t32 / 1e9:8.1f} TFLOP/s')
+    for variant, name in ((1, 'direct'), (0, 'lds   ')):
+        tb = timeit(lambda: ops.canonical_mlp_bf16x3(mlp_in, packed, packed_h, raw, variant=variant))
+        print(f'canonical_mlp bf16x3 {name} : {tb:8.2f} ms  {flop / tb / 1e9:8.1f} TFLOP/s (algorithmic)  '
+              f'max|diff vs fp32| = {float((raw[:, :4] - r32[:, :4]).abs().max()):.3e}')
 
 
 if __name__ == '__main__':
