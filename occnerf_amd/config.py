@@ -90,6 +90,9 @@ _DEFAULTS = {
     # build-specific keys
     'smpl_model': 'auto',            # 'auto' | 'synthetic' | directory holding the SMPL pickles
     'max_samples_per_pass': 1 << 26,  # samples resident per pipeline pass (~470 B each)
+    # 'fp32': exact fp32 MFMA (default, the parity/benchmark path); 'bf16x3': split-bf16 MFMA,
+    # ~3x faster MLP, raw logits within ~1e-5 of fp32
+    'mlp_precision': 'fp32',
 }
 
 _cfg = None

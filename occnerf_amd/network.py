@@ -165,8 +165,11 @@ class Network(nn.Module):
             return self._packed
         cm, nr = self.cnl_mlp.module, self.non_rigid_mlp.module
         nr_lin = [m for m in nr.block_mlps if isinstance(m, nn.Linear)]
+        cw, cb = cm.linear_params()
         self._packed = {
-            'cnl': ops.canonical_mlp_pack(*cm.linear_params()),
+            'cnl': ops.canonical_mlp_pack(cw, cb),
+            'cnl_bf16': ops.canonical_mlp_pack_bf16(cw) if self.cfg.get('mlp_precision', 'fp32') == 'bf16x3'
+            else None,
             'nr': ops.nonrigid_pack([m.weight.detach() for m in nr_lin],
                                     [m.bias.detach() for m in nr_lin]),
             'nr_w0': nr_lin[0].weight.detach(), 'nr_b0': nr_lin[0].bias.detach(),
@@ -203,7 +206,10 @@ class Network(nn.Module):
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
             enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution)
         del knn
-        ops.canonical_mlp(mlp_in, pk['cnl'], raw)
+        if pk['cnl_bf16'] is not None:          # opt-in split-bf16 MFMA path (cfg.mlp_precision)
+            ops.canonical_mlp_bf16x3(mlp_in, pk['cnl'], pk['cnl_bf16'], raw)
+        else:
+            ops.canonical_mlp(mlp_in, pk['cnl'], raw)
         del mlp_in
         rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
         return rgb, acc, depth

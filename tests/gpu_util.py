@@ -14,7 +14,7 @@ FRAME_KEYS = ['rays', 'near', 'far', 'bgcolor', 'dst_Rs', 'dst_Ts', 'cnl_gtfms',
               'dst_posevec']
 
 
-def build_network(seed=0, amplify=False, S=128, non_rigid=False, device='cuda:0'):
+def build_network(seed=0, amplify=False, S=128, non_rigid=False, device='cuda:0', mlp_precision='fp32'):
     """Network with the seeded checkpoint loaded (strict), on `device`, in eval mode."""
     from occnerf_amd.network import Network
     cfg = default_cfg()
@@ -23,6 +23,7 @@ def build_network(seed=0, amplify=False, S=128, non_rigid=False, device='cuda:0'
     cfg.perturb = 0.
     cfg.ignore_non_rigid_motions = not non_rigid
     cfg.smpl_model = 'synthetic'
+    cfg.mlp_precision = mlp_precision
     set_cfg(cfg)
     ctx = util.model_context(seed, amplify)
     net = Network()

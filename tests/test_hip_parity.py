@@ -396,6 +396,17 @@ def test_network_end_to_end(case):
     assert out['comp_loss'].numel() == 1
 
 
+def test_network_end_to_end_bf16x3(case):
+    """Opt-in split-bf16 MLP (cfg.mlp_precision='bf16x3') must still meet the 1e-4 pixel gate."""
+    g, ctx, o = case
+    net, _ = build_network(int(g['meta.seed']), bool(g['meta.amplify']), S=int(g['meta.S']),
+                           non_rigid=bool(int(g['meta.non_rigid'])), mlp_precision='bf16x3')
+    out = net(**frame_to_device(g, DEV), iter_val=1e7)
+    tol = 1e-3 if g['meta.amplify'] else 1e-4
+    for k in ('rgb', 'alpha', 'depth'):
+        assert np.abs(out[k].cpu().numpy() - g['out.' + k]).max() <= tol, k
+
+
 def test_reference_state_dict_surface():
     net, ctx = build_network(0, False, S=32)
     keys = list(net.state_dict().keys())
