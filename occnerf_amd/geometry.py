@@ -23,3 +23,60 @@ def farthest_point_sampling(points, ratio):
         sel[i] = j
         d = np.minimum(d, np.sum((pts - pts[j]) ** 2, axis=1))
     return sel
+
+
+def build_knn_clusters(point_base, scale_indices):
+    """Cluster layout for occnerf_msknn_clustered (include/occnerf_hip.h).
+
+    point_base[P,3] float32; scale_indices = [arange(P), fps0, fps1, fps2] (rows of each
+    scale in the reference's order, network.py:239-241).  The points of every scale but the
+    coarsest are grouped by their nearest coarsest-scale point and stored cluster by cluster
+    (ascending original row inside a cluster), each segment padded to a multiple of 4 rows
+    with +inf points; float4.w carries the point's ORIGINAL row within its scale (as int
+    bits), which is what the search reports and breaks distance ties on.
+
+    Returns dict of numpy arrays: points[M,4] f32, index_map[sum sizes] i32 (original order),
+    centers[ncl,4] f32, ranges[nscale-1,ncl,2] i32, radius[nscale-1,ncl] f32,
+    coarse_rows (begin, end), orig_begin[nscale]."""
+    base = np.ascontiguousarray(point_base, dtype=np.float32)
+    sets = [np.asarray(s, dtype=np.int64) for s in scale_indices]
+    nscale = len(sets)
+    cidx = sets[-1]
+    centers64 = base[cidx].astype(np.float64)
+    ncl = len(cidx)
+    rows, ranges = [], np.zeros((nscale - 1, ncl, 2), np.int32)
+    radius = np.zeros((nscale - 1, ncl), np.float32)
+    cursor = 0
+
+    def emit(pts, orig_rows):
+        nonlocal cursor
+        n = len(orig_rows)
+        pad = (-n) % 4
+        blk = np.full((n + pad, 4), np.inf, np.float32)
+        blk[:n, :3] = pts
+        w = np.zeros(n + pad, np.int32)
+        w[:n] = orig_rows
+        blk[:, 3] = w.view(np.float32)
+        rows.append(blk)
+        begin = cursor
+        cursor += n + pad
+        return begin, cursor
+
+    for l in range(nscale - 1):
+        pts = base[sets[l]]
+        d = np.linalg.norm(pts.astype(np.float64)[:, None, :] - centers64[None, :, :], axis=-1)
+        owner, dmin = d.argmin(1), d.min(1)
+        for k in range(ncl):
+            members = np.nonzero(owner == k)[0]
+            if len(members) == 0:
+                ranges[l, k] = (cursor, cursor)
+                continue
+            ranges[l, k] = emit(pts[members], members)
+            radius[l, k] = np.float32(dmin[members].max() * (1 + 1e-6) + 1e-7)
+    coarse = emit(base[cidx], np.arange(ncl))
+    centers = np.zeros((ncl, 4), np.float32)
+    centers[:, :3] = base[cidx]
+    orig_begin = np.cumsum([0] + [len(s) for s in sets[:-1]]).astype(np.int32)
+    return {'points': np.concatenate(rows, 0), 'index_map': np.concatenate(sets).astype(np.int32),
+            'centers': centers, 'ranges': ranges, 'radius': radius,
+            'coarse_rows': np.array(coarse, np.int32), 'orig_begin': orig_begin, 'ncl': ncl}

@@ -151,7 +151,12 @@ class Network(nn.Module):
         as_sets = [set(s.tolist()) for s in sets]
         seed = [int(l + 1 < len(sets) and as_sets[l + 1] <= as_sets[l]) for l in range(len(sets))]
         normals = self.point_norms.to(dev).double().contiguous()
+        cl = geometry.build_knn_clusters(base.cpu().numpy(), [s.numpy() for s in sets])
+        clusters = {k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if k in
+                        ('points', 'index_map', 'centers', 'ranges', 'radius') else v)
+                    for k, v in cl.items()}
         self._ctx = {
+            'clusters': clusters,
             'device': dev, 'points': pts4, 'index_map': torch.cat(imap).int().to(dev),
             'scale_begin': begin, 'seed': seed, 'normals': normals,
             'unit': ops.unit_normals(normals),
@@ -200,7 +205,10 @@ class Network(nn.Module):
         pk = self._packed_weights()
         if not cfg.ignore_non_rigid_motions:
             xyz = ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
-        knn = ops.msknn(xyz, ctx['points'], ctx['index_map'], ctx['scale_begin'], ctx['seed'])
+        if cfg.get('knn_culling', True):     # same results, ~5x fewer distance evaluations
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'])
+        else:
+            knn = ops.msknn(xyz, ctx['points'], ctx['index_map'], ctx['scale_begin'], ctx['seed'])
         mlp_in, raw, _ = ops.sample_features(
             xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],

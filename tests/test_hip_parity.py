@@ -214,6 +214,42 @@ def test_msknn_bit_exact(case, ops):
     same(got2, got, 'knn without radius carry-over')
 
 
+def _clusters(ctx):
+    from occnerf_amd import geometry
+    sets = [np.arange(len(ctx['point_base']))] + [np.asarray(f) for f in ctx['fps']]
+    cl = geometry.build_knn_clusters(ctx['point_base'], sets)
+    return {k: (T(v) if k in ('points', 'index_map', 'centers', 'ranges', 'radius') else v) for k, v in cl.items()}
+
+
+def test_msknn_clustered_bit_exact(case, ops):
+    """Cluster culling changes the work, never the result."""
+    g, ctx, o = case
+    cl = _clusters(ctx)
+    S = int(g['meta.S'])
+    n = o['xyz'].shape[0] // S
+    for seed in ([1, 1, 1, 0], [0, 0, 0, 0]):
+        got = ops.msknn_clustered(T(o['xyz']), n, S, cl, seed).cpu().numpy()
+        same(got, o['knn'], f'clustered knn vs oracle (seed={seed})')
+    gotg = ops.msknn_clustered(T(g['cnl.xyz']), n, S, cl, [1, 1, 1, 0]).cpu().numpy()
+    same(gotg, g['cnl.knn_idxs'].astype(np.int32), 'clustered knn vs reference golden')
+
+
+def test_msknn_clustered_edge_cases(ops, oracle):
+    ctx = util.model_context(0, False)
+    cl = _clusters(ctx)
+    rng = np.random.RandomState(7)
+    base = ctx['point_base']
+    for n_rays, S in ((37, 13), (5, 128), (64, 8), (1, 1)):      # ragged tiles in both directions
+        N = n_rays * S
+        q = np.concatenate([rng.uniform(-1.5, 1.5, (N - N // 2, 3)),
+                            base[rng.randint(0, len(base), N // 2)] + rng.randn(N // 2, 3) * 1e-6]).astype(np.float32)
+        q[::7] = base[rng.randint(0, len(base), len(q[::7]))]            # exact hits (distance 0)
+        q[1::11] = rng.uniform(-40, 40, (len(q[1::11]), 3))              # far outside
+        rng.shuffle(q)
+        got = ops.msknn_clustered(T(q), n_rays, S, cl, [1, 1, 1, 0]).cpu().numpy()
+        same(got, oracle.msknn(q, base, ctx['fps'], k=10), f'clustered knn {n_rays}x{S}')
+
+
 def test_msknn_edge_cases(ops, oracle):
     ctx = util.model_context(0, False)
     m = _dev_model(ctx, ops)

@@ -47,5 +47,32 @@ def main():
               f'max|diff vs fp32| = {float((raw[:, :4] - r32[:, :4]).abs().max()):.3e}')
 
 
+def bench_frame_stages():
+    """knn variants on the real benchmark frame (needs the whole pipeline up to xyz)."""
+    from occnerf_amd import synth
+    from tests.gpu_util import build_network, frame_to_device
+    net, ctx = build_network(0, False, S=128, non_rigid=True)
+    frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
+    data = frame_to_device(frame, 'cuda:0')
+    c = net._context()
+    import time
+    for culling in (False, True):
+        net.cfg.knn_culling = culling
+        net(**data, iter_val=1e7)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out = net(**data, iter_val=1e7)
+        torch.cuda.synchronize()
+        print(f'frame, knn_culling={culling}: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms')
+        if culling:
+            assert torch.equal(out['rgb'], ref['rgb'])
+        ref = out
+
+
 if __name__ == '__main__':
+    if '--frame' in sys.argv:
+        sys.argv.remove('--frame')
+        bench_frame_stages()
+        sys.exit(0)
     main()
