@@ -70,7 +70,34 @@ def bench_frame_stages():
         ref = out
 
 
+def bench_knn():
+    """kNN variants alone on the benchmark frame's canonical sample positions."""
+    from occnerf_amd import synth
+    from tests.gpu_util import build_network, frame_to_device
+    net, ctx = build_network(0, False, S=128, non_rigid=True)
+    frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
+    data = frame_to_device(frame, 'cuda:0')
+    grabbed = {}
+    real = ops.msknn_clustered
+
+    def grab(xyz, n_rays, S, cl, seed):
+        grabbed.update(xyz=xyz.clone(), n=n_rays, S=S, cl=cl, seed=seed)
+        return real(xyz, n_rays, S, cl, seed)
+    ops.msknn_clustered = grab
+    net(**data, iter_val=1e7)
+    ops.msknn_clustered = real
+    c = net._context()
+    x, n, S, cl, seed = grabbed['xyz'], grabbed['n'], grabbed['S'], grabbed['cl'], grabbed['seed']
+    tb = timeit(lambda: ops.msknn(x, c['points'], c['index_map'], c['scale_begin'], c['seed']))
+    tc = timeit(lambda: ops.msknn_clustered(x, n, S, cl, seed))
+    print(f'msknn brute     : {tb:8.2f} ms')
+    print(f'msknn clustered : {tc:8.2f} ms')
+
+
 if __name__ == '__main__':
+    if '--knn' in sys.argv:
+        bench_knn()
+        sys.exit(0)
     if '--frame' in sys.argv:
         sys.argv.remove('--frame')
         bench_frame_stages()
