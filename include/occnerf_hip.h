@@ -113,7 +113,8 @@ int occnerf_msknn(const float *xyz, int64_t N, const float *points, const int32_
 
 /* The same search with cluster culling (same results, ~5x fewer distance evaluations on the
  * SMPL body).  Queries are xyz[n_rays * samples_per_ray, 3] in ray-major order; a wavefront
- * works on 32 neighbouring rays x 8 consecutive samples and skips every cluster of support
+ * works on 64 consecutive rays x 4 consecutive samples (callers that order rays in compact pixel
+ * patches get the most out of it; any order is correct) and skips every cluster of support
  * points that the triangle inequality puts outside all of its queries' search radii.
  * Layout (built by the host once per model, occnerf_amd/geometry.py::build_knn_clusters):
  * points[M,4] = every scale but the coarsest stored cluster by cluster (cluster = nearest

@@ -149,8 +149,9 @@ __global__ __launch_bounds__(256) void msknn_kernel(const float *__restrict__ xy
 // ---------------------------------------------------------------------------------------
 // Cluster-culled search.  The support points of every scale are grouped by their nearest
 // coarsest-scale point (108 clusters for the SMPL body) and stored cluster by cluster; a
-// wave owns a compact tile of queries -- 32 neighbouring rays x 8 consecutive samples, a box
-// of roughly 15 x 19 x 0.5 cm in observation space -- and skips a whole cluster when, for every
+// wave owns a compact tile of queries -- 64 neighbouring rays (an 8x8 pixel patch when the host
+// orders rays along a Morton curve, Network.forward) x 4 consecutive samples, a box of roughly
+// 4 x 4 x 10 cm in observation space -- and skips a whole cluster when, for every
 // one of its 256 queries, the triangle inequality puts all of the cluster's points outside the
 // current search radius:  |q - c| - r_cluster > radius(q).  Measured on the benchmark frame
 // this leaves ~1 670 of the 9 152 distance evaluations per sample.  Exactness is unchanged:
@@ -201,13 +202,15 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     const int2 *__restrict__ ranges /*[nscale-1][ncl]*/, const float *__restrict__ radius /*[nscale-1][ncl]*/,
     ClusteredScales sc, int32_t *__restrict__ knn_idxs) {
     const int lane = threadIdx.x & 63;
-    const int tiles_per_chunk = (S + 7) / 8;
-    const int64_t n_tiles = ((n_rays + 31) / 32) * tiles_per_chunk;
+    const int tiles_per_chunk = (S + 3) / 4;
+    const int64_t n_tiles = ((n_rays + 63) / 64) * tiles_per_chunk;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
-        const int64_t ray = (tile / tiles_per_chunk) * 32 + (lane & 31);
-        const int s0 = (int)(tile % tiles_per_chunk) * 8 + (lane >> 5) * 4;
+        // lane = one of 64 neighbouring rays (the host orders rays in compact pixel patches),
+        // its 4 queries = 4 consecutive samples of that ray
+        const int64_t ray = (tile / tiles_per_chunk) * 64 + lane;
+        const int s0 = (int)(tile % tiles_per_chunk) * 4;
         int64_t qi[kQ];
         bool live[kQ];
         f32x2 qx[2], qy[2], qz[2];
@@ -421,7 +424,7 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, int64_t n_rays, int32_t sa
         sc.orig_begin[l] = l < nscale ? h_orig_begin[l] : 0;
         sc.seed[l] = (l < nscale && h_seed_from_coarser) ? h_seed_from_coarser[l] : 0;
     }
-    const int64_t tiles = ((n_rays + 31) / 32) * ((samples_per_ray + 7) / 8);
+    const int64_t tiles = ((n_rays + 63) / 64) * ((samples_per_ray + 3) / 4);
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > (int64_t)kNumCU * 16) blocks = (int64_t)kNumCU * 16;
     hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz,

@@ -223,6 +223,33 @@ class Network(nn.Module):
         return rgb, acc, depth
 
     @staticmethod
+    def _ray_patch_order(rays_d):
+        """Permutation that walks the rays along a 2-D Morton curve of their directions (projected
+        on the plane normal to the mean direction): 64 consecutive rays then form a compact
+        ~8x8 pixel patch, which is what the kNN tiles and the hash-grid gathers want.  Rays are
+        independent, so the order is free; outputs are returned in the caller's order.
+        All on the device, no host sync."""
+        d = rays_d / rays_d.norm(dim=1, keepdim=True).clamp_min(1e-20)
+        m = d.mean(dim=0)
+        axis = torch.zeros(3, device=d.device, dtype=d.dtype).scatter_(0, m.abs().argmin().view(1), 1.0)
+        e1 = torch.linalg.cross(m, axis)
+        e1 = e1 / e1.norm().clamp_min(1e-20)
+        e2 = torch.linalg.cross(m, e1)
+        e2 = e2 / e2.norm().clamp_min(1e-20)
+        uv = torch.stack([d @ e1, d @ e2], dim=1)
+        lo = uv.min(dim=0, keepdim=True).values
+        span = (uv.max(dim=0, keepdim=True).values - lo).max().clamp_min(1e-20)
+        q = ((uv - lo) / span * 65535.0).long().clamp_(0, 65535)
+
+        def spread(x):                       # 16 bits -> every second bit
+            x = (x | (x << 8)) & 0x00FF00FF
+            x = (x | (x << 4)) & 0x0F0F0F0F
+            x = (x | (x << 2)) & 0x33333333
+            x = (x | (x << 1)) & 0x55555555
+            return x
+        return torch.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1))
+
+    @staticmethod
     def _host3(v):
         if torch.is_tensor(v):
             v = v.detach().cpu().numpy()
@@ -255,7 +282,9 @@ class Network(nn.Module):
 
             rays_o, rays_d = rays
             rays8 = torch.cat([rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float(),
-                               near.reshape(-1, 1).float(), far.reshape(-1, 1).float()], -1).contiguous()
+                               near.reshape(-1, 1).float(), far.reshape(-1, 1).float()], -1)
+            order = self._ray_patch_order(rays8[:, 3:6]) if cfg.get('ray_patch_order', True) else None
+            rays8 = (rays8[order] if order is not None else rays8).contiguous()
             bbox_min = self._host3(kwargs['cnl_bbox_min_xyz'])
             bbox_scale = self._host3(kwargs['cnl_bbox_scale_xyz'])
             bgcolor = self._host3(kwargs['bgcolor'])
@@ -272,6 +301,10 @@ class Network(nn.Module):
                     cond.reshape(-1).float().contiguous(), hann.tolist(), table))
             rgb, acc, depth = (torch.cat(t, 0) if len(outs) > 1 else outs[0][j]
                                for j, t in enumerate(zip(*outs)))
+            if order is not None:            # back to the caller's ray order
+                inv = torch.empty_like(order)
+                inv[order] = torch.arange(order.numel(), device=order.device)
+                rgb, acc, depth = rgb[inv], acc[inv], depth[inv]
         shape = list(rays_d.shape[:-1])
         return {'rgb': rgb.reshape(shape + [3]), 'alpha': acc.reshape(shape),
                 'depth': depth.reshape(shape),
