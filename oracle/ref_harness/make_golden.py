@@ -257,6 +257,36 @@ def run_case(name, img_size, S, amplify, pose=None, orbit_frame=0, non_rigid=Fal
     return g
 
 
+def run_image_case(name, img_size, S, seed=0):
+    """Full small frame through the reference renderer AND its image assembly
+    (run.py:46-63 unpack_to_image, image_util.py:19-20): rows a1 + a21."""
+    print(f'== {name}: full {img_size}x{img_size} frame, S={S}')
+    import run as ref_run                      # the reference's run.py (guarded by __main__)
+    cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions, cfg.chunk = S, 0., True, 32768
+    frame = synth.make_frame(img_size=img_size)
+    net, sd = build_reference_network(seed, False)
+    net.eval()
+    tkeys = ['rays', 'near', 'far', 'bgcolor', 'dst_Rs', 'dst_Ts', 'cnl_gtfms',
+             'motion_weights_priors', 'cnl_bbox_min_xyz', 'cnl_bbox_max_xyz',
+             'cnl_bbox_scale_xyz', 'dst_posevec']
+    data = {k: torch.from_numpy(np.ascontiguousarray(frame[k])) for k in tkeys}
+    with torch.no_grad():
+        out = net(**data, iter_val=cfg.eval_iter)
+    bg = np.array([255., 255., 255.]) / 255.
+    rgb_img, alpha_img, _ = ref_run.unpack_to_image(img_size, img_size, frame['ray_mask'], bg,
+                                                     out['rgb'].numpy(), out['alpha'].numpy())
+    g = {'meta.img_size': img_size, 'meta.S': S, 'meta.amplify': 0, 'meta.non_rigid': 0,
+         'meta.seed': seed, 'meta.bound': float(net.bound), 'meta.orbit_frame': 0,
+         'meta.pose72': np.zeros(72, 'float32'), 'in.ray_mask': frame['ray_mask'],
+         'in.rays': frame['rays'], 'in.near': frame['near'], 'in.far': frame['far'],
+         'in.bgcolor': frame['bgcolor'], 'out.rgb': _np(out['rgb']), 'out.alpha': _np(out['alpha']),
+         'out.depth': _np(out['depth']), 'img.rgb': rgb_img, 'img.alpha': alpha_img,
+         'img.bgcolor': bg}
+    path = os.path.join(OUT_DIR, name + '.npz')
+    np.savez_compressed(path, **g)
+    print('   rays', frame['rays'].shape[1], '-> wrote', path, f'{os.path.getsize(path) / 1e6:.2f} MB')
+
+
 if __name__ == '__main__':
     os.makedirs(OUT_DIR, exist_ok=True)
     which = CASES
@@ -267,5 +297,7 @@ if __name__ == '__main__':
     if 'all' in which or 'freeview' in which:
         run_case('freeview_amp_s32', img_size=32, S=32, amplify=True, pose=synth.seeded_pose(1),
                  orbit_frame=28, non_rigid=True, keep_rays=160)
+    if 'all' in which or 'image' in which:
+        run_image_case('tpose_ri_image32', img_size=32, S=32)
     if 'all' in which or 'tposeamp' in which:
         run_case('tpose_amp_s32', img_size=32, S=32, amplify=True, keep_rays=160)

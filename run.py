@@ -1,0 +1,86 @@
+"""Render entry point with the reference's command line (run.py:246-247, configs/config.py:65-72):
+
+    python run.py --cfg configs/occnerf/synthetic/occnerf.yaml --type {tpose,freeview,movement} [KEY VALUE ...]
+
+Frames go to experiments/<category>/<task>/<subject>/<experiment>/<load_net>/<folder>/NNNNNN.png
+exactly like the reference (run.py:79-81, image_util.py:53-75).  `load_net: seeded[:N]` renders the
+seeded random-init checkpoint (occnerf_amd/checkpoint.py) when no .tar is on disk."""
+import os
+import time
+
+import numpy as np
+import torch
+
+from configs import cfg, args
+cfg.bgcolor = [255., 255., 255.]
+
+from core.data import create_dataloader  # noqa: E402
+from core.nets import create_network  # noqa: E402
+from occnerf_amd.image import ImageWriter, assemble_uint8_device  # noqa: E402
+
+EXCLUDE_KEYS_TO_GPU = ['frame_name', 'img_width', 'img_height', 'ray_mask']
+
+
+def load_network(model):
+    ckpt_path = os.path.join(cfg.logdir, f'{cfg.load_net}.tar')
+    if os.path.exists(ckpt_path):
+        ckpt = torch.load(ckpt_path, map_location='cpu')
+        model.load_state_dict(ckpt['network'], strict=True)
+        print('load network from ', ckpt_path)
+    elif str(cfg.load_net).startswith('seeded'):
+        from occnerf_amd.checkpoint import make_state_dict
+        seed = int(str(cfg.load_net).split(':')[1]) if ':' in str(cfg.load_net) else 0
+        model.load_state_dict(make_state_dict(model.point_base.detach().numpy(), float(model.bound), seed=seed),
+                              strict=True)
+        print(f'seeded random-init checkpoint (seed {seed})')
+    else:
+        raise FileNotFoundError(ckpt_path)
+    return model.cuda().deploy_mlps_to_secondary_gpus()
+
+
+def _render(data_type, folder_name):
+    cfg.perturb = 0.
+    model = create_network()
+    loader = create_dataloader(data_type)
+    model.generate_neural_points(loader.dataset.avg_betas)
+    model = load_network(model).eval()
+    writer = ImageWriter(output_dir=os.path.join(cfg.logdir, str(cfg.load_net).replace(':', '_')),
+                         exp_name=folder_name)
+    t_render, n_rays = 0.0, 0
+    for idx, batch in enumerate(loader):
+        batch = {k: (v[0] if torch.is_tensor(v) or isinstance(v, list) else v) for k, v in batch.items()}
+        data = {k: v.cuda() for k, v in batch.items() if k not in EXCLUDE_KEYS_TO_GPU and torch.is_tensor(v)}
+        ray_index = torch.nonzero(batch['ray_mask'].cuda()).squeeze(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = model(**data, iter_val=cfg.eval_iter)
+        rgb_img, alpha_img = assemble_uint8_device(int(batch['img_width']), int(batch['img_height']), ray_index,
+                                                   np.array(cfg.bgcolor) / 255., out['rgb'], out['alpha'])
+        imgs = [rgb_img] + ([alpha_img] if cfg.show_alpha else [])
+        img_out = torch.cat(imgs, dim=1).cpu().numpy()        # uint8 over PCIe
+        t_render += time.perf_counter() - t0
+        n_rays += int(ray_index.numel())
+        writer.append(img_out, img_name=f'{idx:06d}' if data_type == 'movement' else None)
+    writer.finalize()
+    print(f'{n_rays} rays in {t_render:.3f} s -> {n_rays / max(t_render, 1e-9):.0f} rays/s (PNG writing excluded)')
+
+
+def run_tpose():
+    cfg.ignore_non_rigid_motions = True
+    _render('tpose', 'tpose' if not cfg.render_folder_name else cfg.render_folder_name)
+
+
+def run_freeview():
+    _render('freeview', f'freeview_{cfg.freeview.frame_idx}' if not cfg.render_folder_name else cfg.render_folder_name)
+
+
+def run_movement():
+    _render('movement', 'movement' if not cfg.render_folder_name else cfg.render_folder_name)
+
+
+if __name__ == '__main__':
+    fn = globals().get(f'run_{args.type}')
+    if fn is None:
+        raise SystemExit(f"--type {args.type}: supported here are tpose, freeview, movement")
+    fn()

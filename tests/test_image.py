@@ -1,0 +1,41 @@
+"""Row a21: image assembly after the renderer, against the reference's own unpack_to_image."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_unpack_to_image_byte_identical():
+    from occnerf_amd.image import assemble_uint8_device, unpack_to_image
+    g = util.load_golden('tpose_ri_image32')
+    rgb_img, alpha_img, _ = unpack_to_image(32, 32, g['in.ray_mask'], g['img.bgcolor'], g['out.rgb'], g['out.alpha'])
+    assert np.array_equal(rgb_img, g['img.rgb']) and np.array_equal(alpha_img, g['img.alpha'])
+    idx = torch.nonzero(torch.from_numpy(g['in.ray_mask'])).squeeze(1)
+    q, qa = assemble_uint8_device(32, 32, idx, g['img.bgcolor'], torch.from_numpy(g['out.rgb']),
+                                  torch.from_numpy(g['out.alpha']))
+    assert np.array_equal(q.numpy(), g['img.rgb']) and np.array_equal(qa.numpy(), g['img.alpha'])
+
+
+@pytest.mark.gpu
+def test_run_py_tpose_entry_point(tmp_path):
+    """python run.py --cfg ... --type tpose renders the golden frame: same CLI, same folder layout,
+    pixels within 1 grey level of the reference's PNG (1e-4 float parity -> at most one 8-bit step)."""
+    from PIL import Image
+    g = util.load_golden('tpose_ri_image32')
+    cmd = [sys.executable, os.path.join(ROOT, 'run.py'), '--cfg',
+           os.path.join(ROOT, 'configs/occnerf/synthetic/occnerf.yaml'), '--type', 'tpose',
+           'render_size', '32', 'N_samples', '32']
+    subprocess.check_call(cmd, cwd=str(tmp_path), env={**os.environ, 'PYTHONPATH': ROOT})
+    png = tmp_path / 'experiments' / 'occnerf' / 'synthetic' / 'capsule_body' / 'occnerf' / 'seeded' / 'tpose' / '000000.png'
+    assert png.exists()
+    img = np.asarray(Image.open(png))
+    assert img.shape == (32, 32, 3)
+    assert np.abs(img.astype(int) - g['img.rgb'].astype(int)).max() <= 1
+    assert (img != g['img.rgb']).mean() < 0.01
