@@ -151,11 +151,13 @@ int occnerf_point_sdf(const float *point_cloud, const float *point_base, const d
 
 /* Per-point feature table, occnerf_mlp.py:171-175:
  * table[P,36] = [encode((knn_base+bound)/(2 bound), clamp((sdf+0.2)/0.8,0,1)) (32),
- *                learnable xyz (3), 0]  (row padded to 36 floats = 144 B). */
+ *                learnable xyz (3), 0]  (row padded to 36 floats = 144 B).
+ * h_offsets: optional HOST copy of offsets[L+1]; with it the kernel knows per level whether the
+ * table is dense or a power-of-two hash and skips the generic 32-bit modulo (same indices). */
 int occnerf_point_table(const double *knn_base, const float *point_sdf, const float *learnable,
                         int32_t P, float bound, float two_bound, const float *embeddings,
-                        const int32_t *offsets, uint32_t L, float S, uint32_t H, float *table,
-                        void *stream);
+                        const int32_t *offsets, const int32_t *h_offsets, uint32_t L, float S,
+                        uint32_t H, float *table, void *stream);
 
 /* Per-sample features: neighbour geometry + hash encoding + visibility-softmax
  * aggregation.  Replaces occnerf_mlp.py:144-181 (+ simple_agg :86-126).
@@ -170,8 +172,9 @@ int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs
                             const float *point_base, const double *normals,
                             const double *unit_normals, const float *counter,
                             const float *table, float bound, float two_bound,
-                            const float *embeddings, const int32_t *offsets, uint32_t L, float S,
-                            uint32_t H, const int32_t *geo_idxs, const float *att_in,
+                            const float *embeddings, const int32_t *offsets,
+                            const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
+                            const int32_t *geo_idxs, const float *att_in,
                             float *mlp_in, float *raw, float *enc_in, void *stream);
 
 /* Canonical MLP weights -> MFMA operand order.  h_W/h_b: HOST arrays of the 10 device

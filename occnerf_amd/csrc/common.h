@@ -46,6 +46,18 @@ struct GridLevels {
     uint32_t resolution[kMaxLevels];
 };
 
+// Per-level index mode of the fused D=4 encoder, decided on the host from the level's table size
+// (wave-uniform in the kernel): the generic `index % hashmap_size` of gridencoder.cu:83 costs a
+// ~35-instruction 32-bit urem per corner, 256 of them per sample.
+//   kDense: all 4 dims fit (stride never exceeds the table) -> index < size, the modulo is the
+//           identity;  kHashPow2: hashed level whose size is a power of two -> mask;
+//   kGeneric: anything else -> the reference's loop and modulo.
+enum GridIndexMode : uint32_t { kGridDense = 0, kGridHashPow2 = 1, kGridGeneric = 2 };
+struct GridModes4 {
+    uint32_t mode[kMaxLevels];
+};
+GridModes4 make_grid_modes_d4(uint32_t L, const GridLevels &lv, const uint32_t *h_level_sizes);
+
 GridLevels make_grid_levels(uint32_t L, float S, uint32_t H);
 
 // gridencoder.cu:50-84: dense index while the stride fits, xor-prime hash otherwise;
@@ -73,37 +85,60 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align_cor
     return index % hashmap_size;
 }
 
-// One level of the D=4, C=2 encoder used by the canonical MLP (occnerf_mlp.py:45):
-// 16 corners, float2 features, explicit fma chain in corner order (bit-exact with the
-// oracle's oc_grid_encode_one).  `grid` points at this level's slice of the table.
+// One level of the D=4, C=2 encoder used by the canonical MLP (occnerf_mlp.py:45): 16 corners,
+// float2 features, explicit fma chain in corner order -- bit-exact with the oracle's
+// oc_grid_encode_one and with gridencoder.cu:137-199.  `grid` points at this level's slice.
+// The corner weights ((1*a0)*a1)*a2)*a3 are formed through shared partial products (identical
+// roundings, 28 instead of 48 multiplies) and the index through per-axis partial terms.
 __device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const float2 *grid,
                                                     uint32_t hashmap_size, float scale,
-                                                    uint32_t resolution) {
-    float pos[4];
+                                                    uint32_t resolution, uint32_t mode) {
+    float f[4][2];        // per axis: weight of the lower / upper cell
     uint32_t pg[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        pos[d] = __fmaf_rn(x[d], scale, 0.5f);
-        const float fl = floorf(pos[d]);
+        float pos = __fmaf_rn(x[d], scale, 0.5f);
+        const float fl = floorf(pos);
         pg[d] = (uint32_t)fl;
-        pos[d] -= fl;
+        pos -= fl;
+        f[d][0] = __fsub_rn(1.f, pos);
+        f[d][1] = pos;
+    }
+    // per-axis index terms t[d][lower/upper]
+    uint32_t t[4][2];
+    if (mode == kGridDense) {
+        uint32_t stride = 1;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            t[d][0] = pg[d] * stride;
+            t[d][1] = (pg[d] + 1) * stride;
+            stride *= resolution + 1;
+        }
+    } else if (mode == kGridHashPow2) {
+        constexpr uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            t[d][0] = pg[d] * primes[d];
+            t[d][1] = (pg[d] + 1) * primes[d];
+        }
     }
     float2 r = make_float2(0.f, 0.f);
+    float w01[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w01[i] = __fmul_rn(f[0][i & 1], f[1][i >> 1]);     // (a0 * a1)
 #pragma unroll
     for (uint32_t idx = 0; idx < 16; idx++) {
-        float w = 1.f;
-        uint32_t pl[4];
-#pragma unroll
-        for (uint32_t d = 0; d < 4; d++) {
-            if ((idx & (1u << d)) == 0) {
-                w = __fmul_rn(w, __fsub_rn(1.f, pos[d]));
-                pl[d] = pg[d];
-            } else {
-                w = __fmul_rn(w, pos[d]);
-                pl[d] = pg[d] + 1;
-            }
+        const int b0 = idx & 1, b1 = (idx >> 1) & 1, b2 = (idx >> 2) & 1, b3 = (idx >> 3) & 1;
+        const float w = __fmul_rn(__fmul_rn(w01[b0 | (b1 << 1)], f[2][b2]), f[3][b3]);
+        uint32_t index;
+        if (mode == kGridDense) {
+            index = t[0][b0] + t[1][b1] + t[2][b2] + t[3][b3];
+        } else if (mode == kGridHashPow2) {
+            index = (t[0][b0] ^ t[1][b1] ^ t[2][b2] ^ t[3][b3]) & (hashmap_size - 1);
+        } else {
+            const uint32_t pl[4] = {pg[0] + b0, pg[1] + b1, pg[2] + b2, pg[3] + b3};
+            index = grid_index<4>(0, false, hashmap_size, resolution, pl);
         }
-        const uint32_t index = grid_index<4>(0, false, hashmap_size, resolution, pl);
         const float2 v = grid[index];
         r.x = __fmaf_rn(w, v.x, r.x);
         r.y = __fmaf_rn(w, v.y, r.y);

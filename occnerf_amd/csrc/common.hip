@@ -31,6 +31,27 @@ GridLevels make_grid_levels(uint32_t L, float S, uint32_t H) {
     return lv;
 }
 
+// Index mode per level for D = 4 (see GridIndexMode).  Dense iff the reference's stride loop
+// (gridencoder.cu:70-74) consumes all four dims without exceeding the level's size.
+GridModes4 make_grid_modes_d4(uint32_t L, const GridLevels &lv, const uint32_t *h_level_sizes) {
+    GridModes4 m;
+    for (uint32_t l = 0; l < (uint32_t)kMaxLevels; l++) {
+        m.mode[l] = kGridGeneric;
+        if (l >= L) continue;
+        const uint64_t size = h_level_sizes[l];
+        uint64_t stride = 1;
+        bool all = true;
+        for (int d = 0; d < 4; d++) {
+            if (stride > size) { all = false; break; }
+            stride *= (uint64_t)lv.resolution[l] + 1;
+        }
+        if (all && stride <= size) m.mode[l] = kGridDense;               // hashing never kicks in
+        else if (!(all && stride <= size) && size > 0 && (size & (size - 1)) == 0 && stride > size)
+            m.mode[l] = kGridHashPow2;
+    }
+    return m;
+}
+
 }  // namespace occ
 
 OCC_API int occnerf_abi_version(void) { return OCCNERF_ABI_VERSION; }

@@ -84,7 +84,7 @@ __global__ void point_table_kernel(const double *__restrict__ knn_base,
                                    const float *__restrict__ learnable, int P, float bound,
                                    float two_bound, const float2 *__restrict__ embeddings,
                                    const int32_t *__restrict__ offsets, int L, GridLevels lv,
-                                   float *__restrict__ table) {
+                                   GridModes4 gm, float *__restrict__ table) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     float x[4];
@@ -102,7 +102,7 @@ __global__ void point_table_kernel(const double *__restrict__ knn_base,
         if (!oob) {
             const uint32_t o0 = (uint32_t)offsets[l];
             v = encode_level_d4c2(x, embeddings + o0, (uint32_t)offsets[l + 1] - o0, lv.scale[l],
-                                  lv.resolution[l]);
+                                  lv.resolution[l], gm.mode[l]);
         }
         row[l * 2] = v.x;
         row[l * 2 + 1] = v.y;
@@ -111,6 +111,15 @@ __global__ void point_table_kernel(const double *__restrict__ knn_base,
 #pragma unroll
     for (int c = 0; c < 3; c++) row[32 + c] = learnable[i * 3 + c];
     row[35] = 0.0f;
+}
+
+// host copy of the level offsets -> index modes; without it every level takes the generic path
+static GridModes4 modes_from_host_offsets(uint32_t L, const GridLevels &lv, const int32_t *h_offsets) {
+    uint32_t sizes[kMaxLevels] = {0};
+    if (h_offsets)
+        for (uint32_t l = 0; l < L; l++) sizes[l] = (uint32_t)(h_offsets[l + 1] - h_offsets[l]);
+    GridModes4 gm = make_grid_modes_d4(h_offsets ? L : 0, lv, sizes);
+    return gm;
 }
 
 struct FeatParams {
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(256) void sample_features_kernel(
     const float *__restrict__ point_base, const double *__restrict__ normals,
     const double *__restrict__ unit, const float *__restrict__ counter,
     const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
-    const int32_t *__restrict__ offsets, GridLevels lv, FeatParams prm,
+    const int32_t *__restrict__ offsets, GridLevels lv, GridModes4 gm, FeatParams prm,
     const int32_t *__restrict__ geo_idxs, const float *__restrict__ att_in,
     float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
     const int nk = prm.nscale * kKnn;
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(256) void sample_features_kernel(
             if (!oob) {
                 const uint32_t o0 = (uint32_t)offsets[l];
                 v = encode_level_d4c2(x, embeddings + o0, (uint32_t)offsets[l + 1] - o0,
-                                      lv.scale[l], lv.resolution[l]);
+                                      lv.scale[l], lv.resolution[l], gm.mode[l]);
             }
             *reinterpret_cast<float2 *>(out + 36 + l * 2) = v;
         }
@@ -286,16 +295,18 @@ OCC_API int occnerf_point_sdf(const float *point_cloud, const float *point_base,
 
 OCC_API int occnerf_point_table(const double *knn_base, const float *point_sdf,
                                 const float *learnable, int32_t P, float bound, float two_bound,
-                                const float *embeddings, const int32_t *offsets, uint32_t L, float S,
-                                uint32_t H, float *table, void *stream) {
+                                const float *embeddings, const int32_t *offsets,
+                                const int32_t *h_offsets, uint32_t L, float S, uint32_t H, float *table,
+                                void *stream) {
     using namespace occ;
     OCC_REQUIRE(knn_base && point_sdf && learnable && embeddings && offsets && table, "point_table: null argument");
     OCC_REQUIRE(L >= 1 && L <= 16, "point_table: L=%u unsupported", L);
     if (P <= 0) return 0;
     const GridLevels lv = make_grid_levels(L, S, H);
+    const GridModes4 gm = modes_from_host_offsets(L, lv, h_offsets);
     hipLaunchKernelGGL(point_table_kernel, dim3((P + 255) / 256), dim3(256), 0, as_stream(stream), knn_base,
                        point_sdf, learnable, P, bound, two_bound, reinterpret_cast<const float2 *>(embeddings),
-                       offsets, (int)L, lv, table);
+                       offsets, (int)L, lv, gm, table);
     return check_launch("point_table");
 }
 
@@ -303,8 +314,9 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                                     int32_t nscale, const float *point_base, const double *normals,
                                     const double *unit_normals, const float *counter,
                                     const float *table, float bound, float two_bound,
-                                    const float *embeddings, const int32_t *offsets, uint32_t L,
-                                    float S, uint32_t H, const int32_t *geo_idxs,
+                                    const float *embeddings, const int32_t *offsets,
+                                    const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
+                                    const int32_t *geo_idxs,
                                     const float *att_in, float *mlp_in, float *raw, float *enc_in,
                                     void *stream) {
     using namespace occ;
@@ -315,12 +327,13 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
     OCC_REQUIRE(L == 16, "sample_features: built for the 16-level encoder of occnerf_mlp.py:45 (L=%u)", L);
     if (N <= 0) return 0;
     const GridLevels lv = make_grid_levels(L, S, H);
+    const GridModes4 gm = modes_from_host_offsets(L, lv, h_offsets);
     FeatParams prm{bound, two_bound, nscale, (int)L};
     int64_t blocks = (N + 255) / 256;
     if (blocks > (int64_t)kNumCU * 16) blocks = (int64_t)kNumCU * 16;
     hipLaunchKernelGGL(sample_features_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, N,
                        knn_idxs, point_base, normals, unit_normals, counter,
                        reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),
-                       offsets, lv, prm, geo_idxs, att_in, mlp_in, raw, enc_in);
+                       offsets, lv, gm, prm, geo_idxs, att_in, mlp_in, raw, enc_in);
     return check_launch("sample_features");
 }

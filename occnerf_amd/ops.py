@@ -58,6 +58,22 @@ def _host_i32(vals):
     return a, a.ctypes.data_as(C.c_void_p)
 
 
+_host_offsets_cache = {}
+
+
+def _host_offsets(offsets):
+    """Host copy of a (constant) level-offset tensor, fetched once per tensor."""
+    key = (offsets.data_ptr(), offsets.shape[0], offsets._version)
+    hit = _host_offsets_cache.get(key)
+    if hit is None:
+        a = np.ascontiguousarray(offsets.detach().cpu().numpy().astype(np.int32))
+        hit = (a, a.ctypes.data_as(C.c_void_p))
+        if len(_host_offsets_cache) > 64:
+            _host_offsets_cache.clear()
+        _host_offsets_cache[key] = hit
+    return hit[1]
+
+
 def _ptr_table(tensors, name):
     ptrs = [_chk(t, torch.float32, f'{name}[{i}]') for i, t in enumerate(tensors)]
     arr = (C.c_void_p * len(ptrs))(*ptrs)
@@ -218,7 +234,8 @@ def point_table(knn_base, sdf, learnable, bound32, two_bound32, embeddings, offs
             _chk(knn_base, torch.float64, 'knn_base'), _chk(sdf, torch.float32, 'point_sdf'),
             _chk(learnable, torch.float32, 'learnable'), P, float(bound32), float(two_bound32),
             _chk(embeddings, torch.float32, 'embeddings'), _chk(offsets, torch.int32, 'offsets'),
-            int(offsets.shape[0] - 1), float(S), int(H), table.data_ptr(), _stream(knn_base))
+            _host_offsets(offsets), int(offsets.shape[0] - 1), float(S), int(H), table.data_ptr(),
+            _stream(knn_base))
     _lib.check(rc, 'point_table')
     return table
 
@@ -238,8 +255,8 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
             _chk(normals, torch.float64, 'normals'), _chk(unit, torch.float64, 'unit_normals'),
             _opt(counter, torch.float32, 'counter'), _chk(table, torch.float32, 'table'),
             float(bound32), float(two_bound32), _chk(embeddings, torch.float32, 'embeddings'),
-            _chk(offsets, torch.int32, 'offsets'), int(offsets.shape[0] - 1), float(S), int(H),
-            _opt(geo_idxs, torch.int32, 'geo_idxs'), _opt(att_in, torch.float32, 'att_in'),
+            _chk(offsets, torch.int32, 'offsets'), _host_offsets(offsets), int(offsets.shape[0] - 1),
+            float(S), int(H), _opt(geo_idxs, torch.int32, 'geo_idxs'), _opt(att_in, torch.float32, 'att_in'),
             mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
             None if enc_in is None else enc_in.data_ptr(), _stream(xyz))
     _lib.check(rc, 'sample_features')

@@ -94,7 +94,31 @@ def bench_knn():
     print(f'msknn clustered : {tc:8.2f} ms')
 
 
+def bench_stage(name):
+    """Time one pipeline op in isolation on the benchmark frame (inputs grabbed from a real forward)."""
+    from occnerf_amd import synth
+    from tests.gpu_util import build_network, frame_to_device
+    net, ctx = build_network(0, False, S=128, non_rigid=True)
+    frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
+    data = frame_to_device(frame, 'cuda:0')
+    real = getattr(ops, name)
+    grabbed = {}
+
+    def grab(*a, **k):
+        grabbed['a'] = tuple(x.clone() if torch.is_tensor(x) else x for x in a)
+        grabbed['k'] = {kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in k.items()}
+        return real(*a, **k)
+    setattr(ops, name, grab)
+    net(**data, iter_val=1e7)
+    setattr(ops, name, real)
+    t = timeit(lambda: real(*grabbed['a'], **grabbed['k']), n=5)
+    print(f'{name:24s}: {t:8.3f} ms')
+
+
 if __name__ == '__main__':
+    if '--stage' in sys.argv:
+        bench_stage(sys.argv[sys.argv.index('--stage') + 1])
+        sys.exit(0)
     if '--knn' in sys.argv:
         bench_knn()
         sys.exit(0)
