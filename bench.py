@@ -101,7 +101,8 @@ def main():
     ops.canonical_mlp = timed_mlp
 
     def step():
-        out = net(**data, iter_val=1e7)
+        with torch.no_grad():
+            out = net(**data, iter_val=1e7)
         packed = torch.cat([out['rgb'], out['alpha'][:, None], out['depth'][:, None]], dim=1)
         if world > 1:                                  # shards of different frames differ in size
             sizes = [torch.zeros(1, dtype=torch.long, device=dev) for _ in range(world)]

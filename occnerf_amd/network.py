@@ -265,8 +265,9 @@ class Network(nn.Module):
         dst_Rs, dst_Ts = dst_Rs[None], dst_Ts[None]
         dst_posevec, cnl_gtfms = dst_posevec[None], cnl_gtfms[None]
         motion_weights_priors = motion_weights_priors[None]
+        want_grad = torch.is_grad_enabled()      # autograd path (training) vs fused HIP path (render)
 
-        with torch.no_grad():
+        with torch.set_grad_enabled(want_grad):
             # ---- per frame, torch (network.py:557-596) ----
             if iter_val >= cfg.pose_decoder.get('kick_in_iter', 0):
                 refined = self.pose_decoder(dst_posevec)['Rs']
@@ -285,27 +286,43 @@ class Network(nn.Module):
                                near.reshape(-1, 1).float(), far.reshape(-1, 1).float()], -1)
             order = self._ray_patch_order(rays8[:, 3:6]) if cfg.get('ray_patch_order', True) else None
             rays8 = (rays8[order] if order is not None else rays8).contiguous()
-            bbox_min = self._host3(kwargs['cnl_bbox_min_xyz'])
-            bbox_scale = self._host3(kwargs['cnl_bbox_scale_xyz'])
-            bgcolor = self._host3(kwargs['bgcolor'])
-            table = self._point_stage(self._context())
-
-            # ---- per sample, HIP; all rays of the frame in as few passes as memory allows ----
             S = int(cfg.N_samples)
-            rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 26)) // S)
             outs = []
-            for i in range(0, rays8.shape[0], rays_per_pass):
-                outs.append(self._render_rays(
-                    rays8[i:i + rays_per_pass], Rs[0].contiguous(), Ts[0].contiguous(),
-                    vol.contiguous(), bbox_min, bbox_scale, bgcolor,
-                    cond.reshape(-1).float().contiguous(), hann.tolist(), table))
-            rgb, acc, depth = (torch.cat(t, 0) if len(outs) > 1 else outs[0][j]
-                               for j, t in enumerate(zip(*outs)))
+            if want_grad:
+                # ---- differentiable path: torch autograd over HIP kNN + HIP grid encoder ----
+                from . import train_path
+                bmin = torch.as_tensor(self._host3(kwargs['cnl_bbox_min_xyz']), device=dev)
+                bscale = torch.as_tensor(self._host3(kwargs['cnl_bbox_scale_xyz']), device=dev)
+                bg = torch.as_tensor(self._host3(kwargs['bgcolor']), device=dev)
+                t_rand = kwargs.get('t_rand')            # optional injected jitter [R,S] (tests)
+                if t_rand is not None and order is not None:
+                    t_rand = t_rand[order]
+                for i in range(0, rays8.shape[0], int(cfg.chunk)):
+                    outs.append(train_path.render_rays_autograd(
+                        self, rays8[i:i + cfg.chunk], Rs[0], Ts[0], vol, bmin, bscale, bg, cond.float(),
+                        hann.to(dev), None if t_rand is None else t_rand[i:i + cfg.chunk]))
+            else:
+                bbox_min = self._host3(kwargs['cnl_bbox_min_xyz'])
+                bbox_scale = self._host3(kwargs['cnl_bbox_scale_xyz'])
+                bgcolor = self._host3(kwargs['bgcolor'])
+                table = self._point_stage(self._context())
+                # ---- per sample, HIP; all rays of the frame in as few passes as memory allows ----
+                rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 26)) // S)
+                for i in range(0, rays8.shape[0], rays_per_pass):
+                    outs.append(self._render_rays(
+                        rays8[i:i + rays_per_pass], Rs[0].contiguous(), Ts[0].contiguous(),
+                        vol.contiguous(), bbox_min, bbox_scale, bgcolor,
+                        cond.reshape(-1).float().contiguous(), hann.tolist(), table)
+                        + (torch.zeros(1, 1, device=dev),))
+            rgb, acc, depth, comp_loss = (torch.cat(t, 0) if len(outs) > 1 else outs[0][j]
+                                          for j, t in enumerate(zip(*outs)))
             if order is not None:            # back to the caller's ray order
                 inv = torch.empty_like(order)
                 inv[order] = torch.arange(order.numel(), device=order.device)
                 rgb, acc, depth = rgb[inv], acc[inv], depth[inv]
+                if comp_loss.shape[0] == order.numel():
+                    comp_loss = comp_loss[inv]
         shape = list(rays_d.shape[:-1])
         return {'rgb': rgb.reshape(shape + [3]), 'alpha': acc.reshape(shape),
                 'depth': depth.reshape(shape),
-                'comp_loss': torch.zeros(1, device=dev)}
+                'comp_loss': comp_loss.reshape(-1)}

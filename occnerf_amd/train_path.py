@@ -1,0 +1,164 @@
+"""Differentiable evaluation of the sample path (config 5).
+
+Rendering (no grad) goes through the fused HIP kernels.  When gradients are needed the same
+chain is evaluated here so that torch autograd can differentiate it:
+
+  * the pieces whose results are integers or constants stay HIP: the multi-scale kNN
+    (`ops.msknn_clustered`), the per-point k=3 / visibility k=10 searches (`ops.knn_small`);
+  * the hash-grid encoder is the HIP operator behind an autograd Function
+    (occnerf_amd/gridencoder.py: forward + `grid_encode_backward` with fp32 atomics, and the
+    dy_dx input gradient for the per-point call whose inputs depend on `point_dist`);
+  * the rest (warp via F.grid_sample, MLPs via nn.Linear, aggregation, compositing) is plain
+    torch on the GPU, written to mirror the reference's graph including its `detach()` /
+    `no_grad` cuts: network.py:351-402, 263-284, 320-348, 486-519; occnerf_mlp.py:86-199.
+    Dedicated backward kernels for these are the next step.
+
+One consequence of the reference's cuts worth knowing: `xyz` only enters CanonicalMLP through
+`no_grad` quantities, so the non-rigid MLP receives no gradient from the rendering loss.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def sample_along_rays(rays8, S, perturb, t_rand=None):
+    """network.py:405-432,456 -> z_vals[n,S], pts[n,S,3]."""
+    near, far = rays8[:, 6:7], rays8[:, 7:8]
+    t = torch.linspace(0., 1., steps=S, device=rays8.device)
+    z = near * (1. - t) + far * t
+    if perturb > 0.:
+        mids = .5 * (z[..., 1:] + z[..., :-1])
+        upper = torch.cat([mids, z[..., -1:]], -1)
+        lower = torch.cat([z[..., :1], mids], -1)
+        if t_rand is None:
+            t_rand = torch.rand(z.shape, device=z.device)
+        z = lower + (upper - lower) * t_rand
+    pts = rays8[:, None, 0:3] + rays8[:, None, 3:6] * z[..., None]
+    return z, pts
+
+
+def warp_to_canonical(pts, Rs, Ts, vol, bbox_min, bbox_scale):
+    """network.py:351-402 for all bones at once -> x_skel[n,S,3], mask[n,S,1]."""
+    shape = pts.shape
+    p = pts.reshape(-1, 3)
+    nb = Rs.shape[0]
+    pos = torch.einsum('bij,nj->bni', Rs, p) + Ts[:, None, :]                    # [nb,N,3]
+    grid = (pos - bbox_min[None, None, :]) * bbox_scale[None, None, :] - 1.0
+    w = F.grid_sample(vol[:nb, None], grid[:, None, None, :, :], padding_mode='zeros',
+                      align_corners=True)[:, 0, 0, 0, :]                         # [nb,N]
+    wsum = w.sum(0)[:, None]
+    x_skel = (w[..., None] * pos).sum(0) / wsum.clamp(min=0.0001)
+    return x_skel.reshape(shape), wsum.reshape(shape[0], shape[1], 1)
+
+
+def point_sdf_block(net):
+    """network.py:263-284 with gradients to point_dist -> knn_base[P,3] (f64), dist[P,1]."""
+    pc = net.point_cloud.float()
+    base = net.point_base.detach()
+    kidx = ops.knn_small(pc.detach().contiguous(), base, 3).long()
+    nbr = base[kidx]                                                             # [P,3,3]
+    direction = pc[:, None, :] - nbr
+    norms = net.point_norms.to(pc.device)[kidx]                                  # float64
+    att = torch.abs(F.cosine_similarity(direction, norms, dim=-1))[..., None]
+    knn_base = (att * nbr).sum(1) / att.sum(1)
+    inside = (torch.einsum('ijk,ijk->ij', direction.float(), norms.float()) < 0).sum(1) > 1.5
+    dist = torch.norm(direction, dim=-1).mean(1, keepdim=True)
+    dist = torch.where(inside[:, None], -dist, dist)
+    return knn_base, dist
+
+
+def canonical_mlp_torch(cm, xyz, knn_idxs, net, knn_base, point_sdf):
+    """occnerf_mlp.py:142-199 -> raw[N,5].  cm: CanonicalMLP (parameters), knn_idxs[N,4,10]."""
+    N, k = knn_idxs.shape[0], knn_idxs.shape[2]
+    base = net.point_base.detach()
+    idx0 = knn_idxs[:, 0].long()
+    knn_points = base[idx0]                                                      # [N,10,3]
+    normals = net.point_norms.to(xyz.device)[idx0]                               # float64
+    with torch.no_grad():
+        direction = xyz[:, None, :] - knn_points
+        inside = (torch.einsum('ijk,ijk->ij', direction.double(), normals.double()) < 0).sum(1) > k * 0.5
+        dist = torch.norm(direction, dim=-1).mean(1, keepdim=True)
+        dist = torch.where(inside[:, None], -dist, dist)
+        normed = torch.clamp((dist + 0.2) / 0.5, 0.0, 1.0)
+    bound = cm.bound
+    pn = (knn_points + bound) / (2 * bound)
+    att = torch.abs(F.cosine_similarity(direction[:, :3], normals[:, :3], dim=-1))[..., None]
+    q = (att * pn[:, :3]).sum(1) / att.sum(1)
+    h = cm.encoder(torch.cat((q, normed), dim=-1).float(), bound=None)
+
+    pc01 = (knn_base + bound) / (2 * bound)
+    sdf01 = torch.clamp((point_sdf + 0.2) / 0.8, 0.0, 1.0)
+    feats = cm.encoder(torch.cat((pc01, sdf01), dim=-1).float(), bound=None)
+    feats = torch.cat((feats, net.point_cloud.float()), dim=-1)                  # [P,35]
+    gathered = feats[knn_idxs.long()].view(N, -1, feats.shape[-1])               # [N,40,35]
+    atts = net.point_counter.detach()[knn_idxs.long()].view(N, -1, 1).clone()
+    atts = atts + (1. - atts.min(dim=1, keepdim=True)[0])
+    atts = atts / atts.max(dim=1, keepdim=True)[0]
+    var = torch.var(atts, dim=1)
+    atts = F.softmax(atts, dim=1)
+    agg = torch.sum(atts.detach() * gathered, dim=1)
+
+    enc = h
+    z = torch.cat([agg, var, enc], dim=-1).float()
+    for layer in cm.pts_linears:
+        z = layer(z)
+    z = cm.geo_linear(z)
+    sigma = z[..., [0]]
+    z = torch.cat([z[..., 1:], agg, enc], dim=-1)
+    for layer in cm.rgb_linears:
+        z = layer(z)
+    rgb = cm.output_linear(z)
+    return torch.cat((rgb, sigma, dist.detach()), dim=-1)
+
+
+def raw2outputs(raw, mask, z_vals, rays_d, bgcolor):
+    """network.py:320-348."""
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], dim=-1)
+    dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
+    rgb = torch.sigmoid(raw[..., :3])
+    alpha = (1.0 - torch.exp(-F.softplus(raw[..., 3]) * dists)) * mask[:, :, 0]
+    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1. - alpha + 1e-10], dim=-1), dim=-1)[:, :-1]
+    weights = alpha * trans
+    rgb_map = torch.sum(weights[..., None] * rgb, -2)
+    term = torch.argmax(alpha, dim=1, keepdim=True)
+    depth = torch.sum(weights * z_vals, -1)
+    acc = torch.sum(weights, -1)
+    rgb_map = rgb_map + (1. - acc[..., None]) * bgcolor[None, :] / 255.
+    return rgb_map, acc, depth, term
+
+
+def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, t_rand=None):
+    """Differentiable counterpart of Network._render_rays (+ the training branch a18)."""
+    cfg, ctx = net.cfg, net._context()
+    S = int(cfg.N_samples)
+    n = rays8.shape[0]
+    z, pts = sample_along_rays(rays8, S, float(cfg.perturb), t_rand)
+    cnl_pts, mask = warp_to_canonical(pts, Rs, Ts, vol, bbox_min, bbox_scale)
+    xyz = cnl_pts.reshape(-1, 3)
+    if not cfg.ignore_non_rigid_motions:
+        nr = net.non_rigid_mlp.module
+        emb = torch.cat([hann[j] * fn(xyz * float(2 ** j)) for j in range(int(cfg.non_rigid_motion_mlp.multires))
+                         for fn in (torch.sin, torch.cos)], dim=-1)
+        xyz = nr(pos_embed=emb, pos_xyz=xyz, condition_code=cond.expand(xyz.shape[0], -1))['xyz']
+    with torch.no_grad():
+        knn = ops.msknn_clustered(xyz.detach().float().contiguous(), n, S, ctx['clusters'], ctx['seed'])
+    knn_base, sdf = point_sdf_block(net)
+    raw = canonical_mlp_torch(net.cnl_mlp.module, xyz, knn, net, knn_base, sdf).reshape(n, S, 5)
+    rgb, acc, depth, term = raw2outputs(raw, mask, z, rays8[:, 3:6], bgcolor)
+
+    if net.training:                                                             # network.py:486-517
+        dist, sigma = raw[..., 4:], raw[..., [3]]
+        comp_loss = (dist < 0.).float().detach() * torch.exp(torch.clamp(-F.relu(sigma), min=-10, max=0))
+        comp_loss = comp_loss.squeeze(-1) * 10.
+        depth_mask = depth.detach() > 0.5
+        if int(depth_mask.sum()) > 1:
+            tp = term[depth_mask].detach()
+            term_pts = torch.gather(cnl_pts[depth_mask].detach(), 1, tp[:, :, None].expand(-1, 1, 3)).squeeze(1)
+            kidx = ops.knn_small(term_pts.float().contiguous(), net.point_cloud.detach().float().contiguous(), 10)
+            net.point_counter.data[kidx.view(-1).long()] += 1.                   # duplicates count once
+    else:
+        comp_loss = torch.zeros(1, 1, device=rays8.device)
+    return rgb, acc, depth, comp_loss

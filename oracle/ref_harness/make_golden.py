@@ -257,6 +257,59 @@ def run_case(name, img_size, S, amplify, pose=None, orbit_frame=0, non_rigid=Fal
     return g
 
 
+def run_train_case(name, img_size=32, S=32, keep_rays=96, seed=0):
+    """Training-mode forward + backward of the reference (rows a18/a19, config 5): stratified
+    jitter with an injected t_rand, comp_loss, the point_counter visibility update, and the
+    gradients of a scalar loss w.r.t. a spread of parameters."""
+    print(f'== {name}: train mode, {img_size}x{img_size}, S={S}')
+    cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions, cfg.chunk = S, 1., False, 32768
+    pose72 = synth.seeded_pose(2)
+    frame = synth.make_frame(img_size=img_size, pose72=pose72, orbit_frame=7)
+    R = frame['rays'].shape[1]
+    sel = np.linspace(0, R - 1, keep_rays).astype(np.int64)
+    frame['rays'] = frame['rays'][:, sel]
+    frame['near'], frame['far'] = frame['near'][sel], frame['far'][sel]
+    net, sd = build_reference_network(seed, True)
+    net.train()
+    t_rand = torch.rand(keep_rays, S, generator=torch.Generator().manual_seed(123))
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: t_rand.clone()          # network.py:430 is the only caller
+    tkeys = ['rays', 'near', 'far', 'bgcolor', 'dst_Rs', 'dst_Ts', 'cnl_gtfms',
+             'motion_weights_priors', 'cnl_bbox_min_xyz', 'cnl_bbox_max_xyz',
+             'cnl_bbox_scale_xyz', 'dst_posevec']
+    data = {k: torch.from_numpy(np.ascontiguousarray(frame[k])) for k in tkeys}
+    try:
+        out = net(**data, iter_val=cfg.eval_iter)
+    finally:
+        torch.rand = real_rand
+    loss = (out['rgb'] ** 2).mean() + 0.5 * out['alpha'].mean() + 0.01 * out['depth'].mean() \
+        + 0.1 * out['comp_loss'].mean()
+    loss.backward()
+    g = {'meta.img_size': img_size, 'meta.S': S, 'meta.amplify': 1, 'meta.non_rigid': 1,
+         'meta.seed': seed, 'meta.bound': float(net.bound), 'meta.orbit_frame': 7,
+         'meta.pose72': pose72, 'in.rays': frame['rays'], 'in.near': frame['near'],
+         'in.far': frame['far'], 'in.t_rand': t_rand.numpy(), 'out.loss': float(loss)}
+    for k in ('rgb', 'alpha', 'depth', 'comp_loss'):
+        g['out.' + k] = _np(out[k])
+    g['out.point_counter'] = _np(net.point_counter)
+    grads = {n: p.grad for n, p in net.named_parameters()}
+    g['grad.none'] = np.array([n for n, v in grads.items() if v is None])
+    for n in ('point_dist', 'cnl_mlp.module.geo_linear.0.weight', 'cnl_mlp.module.output_linear.0.weight',
+              'cnl_mlp.module.pts_linears.0.weight', 'cnl_mlp.module.rgb_linears.6.bias',
+              'pose_decoder.block_mlps.8.weight', 'mweight_vol_decoder.const_embedding',
+              'mweight_vol_decoder.decoder.block_conv.8.bias'):
+        g['grad.' + n] = _np(grads[n])
+    ge = grads['cnl_mlp.module.encoder.embeddings'].reshape(-1)
+    top = torch.topk(ge.abs(), 2000).indices
+    g['grad.emb.idx'], g['grad.emb.val'] = _np(top), _np(ge[top])
+    g['grad.emb.abs_sum'] = float(ge.abs().double().sum())
+    g['grad.emb.nnz'] = int((ge != 0).sum())
+    path = os.path.join(OUT_DIR, name + '.npz')
+    np.savez_compressed(path, **g)
+    print('   loss', float(loss), 'no-grad params:', list(g['grad.none'])[:6], '-> wrote', path,
+          f'{os.path.getsize(path) / 1e6:.2f} MB')
+
+
 def run_image_case(name, img_size, S, seed=0):
     """Full small frame through the reference renderer AND its image assembly
     (run.py:46-63 unpack_to_image, image_util.py:19-20): rows a1 + a21."""
@@ -297,6 +350,8 @@ if __name__ == '__main__':
     if 'all' in which or 'freeview' in which:
         run_case('freeview_amp_s32', img_size=32, S=32, amplify=True, pose=synth.seeded_pose(1),
                  orbit_frame=28, non_rigid=True, keep_rays=160)
+    if 'all' in which or 'train' in which:
+        run_train_case('train_amp_s32')
     if 'all' in which or 'image' in which:
         run_image_case('tpose_ri_image32', img_size=32, S=32)
     if 'all' in which or 'tposeamp' in which:

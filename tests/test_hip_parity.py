@@ -422,7 +422,8 @@ def test_network_end_to_end(case):
     g, ctx, o = case
     net, _ = build_network(int(g['meta.seed']), bool(g['meta.amplify']), S=int(g['meta.S']),
                            non_rigid=bool(int(g['meta.non_rigid'])))
-    out = net(**frame_to_device(g, DEV), iter_val=1e7)
+    with torch.no_grad():
+        out = net(**frame_to_device(g, DEV), iter_val=1e7)
     tol = 1e-3 if g['meta.amplify'] else 1e-4
     for k in ('rgb', 'alpha', 'depth'):
         got = out[k].cpu().numpy()
@@ -437,10 +438,62 @@ def test_network_end_to_end_bf16x3(case):
     g, ctx, o = case
     net, _ = build_network(int(g['meta.seed']), bool(g['meta.amplify']), S=int(g['meta.S']),
                            non_rigid=bool(int(g['meta.non_rigid'])), mlp_precision='bf16x3')
-    out = net(**frame_to_device(g, DEV), iter_val=1e7)
+    with torch.no_grad():
+        out = net(**frame_to_device(g, DEV), iter_val=1e7)
     tol = 1e-3 if g['meta.amplify'] else 1e-4
     for k in ('rgb', 'alpha', 'depth'):
         assert np.abs(out[k].cpu().numpy() - g['out.' + k]).max() <= tol, k
+
+
+def test_autograd_path_matches_render_path(case):
+    """With gradients enabled Network.forward takes the differentiable route (torch autograd over
+    the HIP kNN and the HIP grid-encoder Function); in eval mode it must render the same image."""
+    g, ctx, o = case
+    net, _ = build_network(int(g['meta.seed']), bool(g['meta.amplify']), S=int(g['meta.S']),
+                           non_rigid=bool(int(g['meta.non_rigid'])))
+    data = frame_to_device(g, DEV)
+    out = net(**data, iter_val=1e7)                      # grad mode
+    assert out['rgb'].requires_grad
+    tol = 1e-3 if g['meta.amplify'] else 1e-4
+    for k in ('rgb', 'alpha', 'depth'):
+        assert np.abs(out[k].detach().cpu().numpy() - g['out.' + k]).max() <= tol, k
+
+
+def test_training_step_against_reference():
+    """Rows a18/a19, config 5: training-mode forward (jitter, comp_loss, visibility counter) and the
+    gradients of a scalar loss, against the reference's own autograd (tests/golden/train_amp_s32)."""
+    from occnerf_amd import synth
+    g = util.load_golden('train_amp_s32')
+    net, ctx = build_network(0, True, S=32, non_rigid=True)
+    net.cfg.perturb = 1.0
+    net.train()
+    frame = synth.make_frame(img_size=32, pose72=g['meta.pose72'], orbit_frame=7)
+    for k in ('rays', 'near', 'far'):
+        frame[k] = g['in.' + k]
+    data = frame_to_device(frame, DEV)
+    out = net(**data, iter_val=1e7, t_rand=T(g['in.t_rand']))
+    for k, tol in (('rgb', 2e-4), ('alpha', 2e-4), ('depth', 1e-3), ('comp_loss', 1e-3)):
+        assert out[k].shape == g['out.' + k].shape, k
+        assert np.abs(out[k].detach().cpu().numpy() - g['out.' + k]).max() <= tol, k
+    same(net.point_counter.detach().cpu().numpy(), g['out.point_counter'], 'point_counter after the step')
+    loss = (out['rgb'] ** 2).mean() + 0.5 * out['alpha'].mean() + 0.01 * out['depth'].mean() \
+        + 0.1 * out['comp_loss'].mean()
+    assert abs(float(loss) - float(g['out.loss'])) <= 1e-4
+    loss.backward()
+    grads = {n: p.grad for n, p in net.named_parameters()}
+    assert sorted(n for n, v in grads.items() if v is None) == sorted(str(x) for x in g['grad.none'])
+    for key in g:
+        if not key.startswith('grad.') or key in ('grad.none',) or key.startswith('grad.emb'):
+            continue
+        name = key[len('grad.'):]
+        want = g[key]
+        got = grads[name].detach().cpu().numpy()
+        scale = max(np.abs(want).max(), 1e-12)
+        assert np.abs(got - want).max() <= 2e-3 * scale + 1e-9, (name, np.abs(got - want).max(), scale)
+    ge = grads['cnl_mlp.module.encoder.embeddings'].reshape(-1)
+    gv = ge[torch.from_numpy(g['grad.emb.idx']).to(DEV)].cpu().numpy()
+    assert np.abs(gv - g['grad.emb.val']).max() <= 2e-3 * np.abs(g['grad.emb.val']).max()
+    assert abs(float(ge.abs().double().sum()) - float(g['grad.emb.abs_sum'])) <= 2e-3 * float(g['grad.emb.abs_sum'])
 
 
 def test_reference_state_dict_surface():
@@ -458,6 +511,7 @@ def test_full_size_properties(ops, oracle):
     net, ctx = build_network(0, False, S=128, non_rigid=True)
     frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
     data = frame_to_device(frame, DEV)
+    torch.set_grad_enabled(False)
     out = net(**data, iter_val=1e7)
     R = frame['rays'].shape[1]
     assert out['rgb'].shape == (R, 3) and out['alpha'].shape == (R,)
@@ -479,5 +533,6 @@ def test_full_size_properties(ops, oracle):
     sub = dict(frame)
     sub['rays'], sub['near'], sub['far'] = frame['rays'][:, sel], frame['near'][sel], frame['far'][sel]
     want = stagewise_oracle_render(None, ctx, frame=sub, S=128, non_rigid=True)
+    torch.set_grad_enabled(True)
     for k in ('rgb', 'alpha', 'depth'):
         assert np.abs(out[k].cpu().numpy()[sel] - want[k]).max() <= 1e-4, k

@@ -47,7 +47,7 @@ def test_network_state_dict_surface_on_cpu():
     assert net.cnl_mlp.module.encoder.embeddings.shape == (7755336, 2)
     assert hasattr(net, 'mweight_vol_decoder') and net.point_cloud.shape == (6890, 3)
     frame = {'rays': torch.zeros(2, 4, 3)}
-    with pytest.raises(RuntimeError, match='GPU'):       # no silent CPU fallback
+    with pytest.raises(RuntimeError, match='GPU'), torch.no_grad():       # no silent CPU fallback
         net(rays=frame['rays'], dst_Rs=torch.zeros(24, 3, 3), dst_Ts=torch.zeros(24, 3),
             cnl_gtfms=torch.zeros(24, 4, 4), motion_weights_priors=torch.ones(25, 32, 32, 32),
             dst_posevec=torch.zeros(69), near=torch.zeros(4, 1), far=torch.ones(4, 1))

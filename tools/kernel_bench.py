@@ -24,6 +24,9 @@ def timeit(fn, n=3):
     return e0.elapsed_time(e1) / n
 
 
+torch.set_grad_enabled(False)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--samples', type=int, default=183784 * 128)
