@@ -472,7 +472,7 @@ def test_training_step_against_reference():
         frame[k] = g['in.' + k]
     data = frame_to_device(frame, DEV)
     out = net(**data, iter_val=1e7, t_rand=T(g['in.t_rand']))
-    for k, tol in (('rgb', 2e-4), ('alpha', 2e-4), ('depth', 1e-3), ('comp_loss', 1e-3)):
+    for k, tol in (('rgb', 2e-4), ('alpha', 2e-4), ('depth', 1e-3), ('comp_loss', 1e-2)):   # comp_loss = 10 exp(-relu(sigma)): 10x the logit tolerance
         assert out[k].shape == g['out.' + k].shape, k
         assert np.abs(out[k].detach().cpu().numpy() - g['out.' + k]).max() <= tol, k
     same(net.point_counter.detach().cpu().numpy(), g['out.point_counter'], 'point_counter after the step')
