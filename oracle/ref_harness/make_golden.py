@@ -257,7 +257,7 @@ def run_case(name, img_size, S, amplify, pose=None, orbit_frame=0, non_rigid=Fal
     return g
 
 
-def run_train_case(name, img_size=32, S=32, keep_rays=96, seed=0):
+def run_train_case(name, img_size=32, S=32, keep_rays=96, seed=0, amplify=True):
     """Training-mode forward + backward of the reference (rows a18/a19, config 5): stratified
     jitter with an injected t_rand, comp_loss, the point_counter visibility update, and the
     gradients of a scalar loss w.r.t. a spread of parameters."""
@@ -269,7 +269,7 @@ def run_train_case(name, img_size=32, S=32, keep_rays=96, seed=0):
     sel = np.linspace(0, R - 1, keep_rays).astype(np.int64)
     frame['rays'] = frame['rays'][:, sel]
     frame['near'], frame['far'] = frame['near'][sel], frame['far'][sel]
-    net, sd = build_reference_network(seed, True)
+    net, sd = build_reference_network(seed, amplify)
     net.train()
     t_rand = torch.rand(keep_rays, S, generator=torch.Generator().manual_seed(123))
     real_rand = torch.rand
@@ -285,7 +285,7 @@ def run_train_case(name, img_size=32, S=32, keep_rays=96, seed=0):
     loss = (out['rgb'] ** 2).mean() + 0.5 * out['alpha'].mean() + 0.01 * out['depth'].mean() \
         + 0.1 * out['comp_loss'].mean()
     loss.backward()
-    g = {'meta.img_size': img_size, 'meta.S': S, 'meta.amplify': 1, 'meta.non_rigid': 1,
+    g = {'meta.img_size': img_size, 'meta.S': S, 'meta.amplify': int(amplify), 'meta.non_rigid': 1,
          'meta.seed': seed, 'meta.bound': float(net.bound), 'meta.orbit_frame': 7,
          'meta.pose72': pose72, 'in.rays': frame['rays'], 'in.near': frame['near'],
          'in.far': frame['far'], 'in.t_rand': t_rand.numpy(), 'out.loss': float(loss)}
@@ -352,6 +352,7 @@ if __name__ == '__main__':
                  orbit_frame=28, non_rigid=True, keep_rays=160)
     if 'all' in which or 'train' in which:
         run_train_case('train_amp_s32')
+        run_train_case('train_ri_s32', amplify=False)
     if 'all' in which or 'image' in which:
         run_image_case('tpose_ri_image32', img_size=32, S=32)
     if 'all' in which or 'tposeamp' in which:
