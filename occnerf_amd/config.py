@@ -86,7 +86,7 @@ _DEFAULTS = {
     'N_samples': 128, 'perturb': 1.0, 'netchunk_per_gpu': 300000, 'chunk': 32768, 'n_gpus': 1,
     'bgcolor': [0.0, 0.0, 0.0], 'resize_img_scale': 0.5, 'show_alpha': False, 'show_truth': False,
     'patch': {'sample_subject_ratio': 0.8, 'N_patches': 6, 'size': 32},
-    'freeview': {'frame_idx': 0}, 'tpose': {}, 'movement': {},
+    'freeview': {'frame_idx': 0}, 'tpose': {}, 'movement': {}, 'train': {},
     # build-specific keys
     'smpl_model': 'auto',            # 'auto' | 'synthetic' | directory holding the SMPL pickles
     'max_samples_per_pass': 1 << 26,  # samples resident per pipeline pass (~470 B each)

@@ -39,3 +39,22 @@ def test_run_py_tpose_entry_point(tmp_path):
     assert img.shape == (32, 32, 3)
     assert np.abs(img.astype(int) - g['img.rgb'].astype(int)).max() <= 1
     assert (img != g['img.rgb']).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_train_py_entry_point(tmp_path):
+    """python train.py --cfg ... runs optimisation steps through the differentiable path, the loss
+    falls, and the checkpoint has the reference's layout and loads back with strict=True."""
+    cmd = [sys.executable, os.path.join(ROOT, 'train.py'), '--cfg',
+           os.path.join(ROOT, 'configs/occnerf/synthetic/occnerf.yaml'), 'render_size', '128', 'N_samples', '32',
+           'train.maxiter', '12', 'train.log_interval', '1', 'patch.size', '16', 'patch.N_patches', '4']
+    out = subprocess.check_output(cmd, cwd=str(tmp_path), env={**os.environ, 'PYTHONPATH': ROOT}, text=True)
+    losses = [float(line.split('loss')[1].split()[0]) for line in out.splitlines() if line.startswith('iter')]
+    assert len(losses) >= 12 and all(np.isfinite(losses))
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])
+    ckpt = torch.load(tmp_path / 'experiments' / 'occnerf' / 'synthetic' / 'capsule_body' / 'occnerf' / 'latest.tar',
+                      map_location='cpu')
+    assert set(ckpt) == {'iter', 'network', 'optimizer'} and ckpt['iter'] == 12
+    from tests.gpu_util import build_network
+    net, ctx = build_network(0, False, S=32, device='cpu')
+    net.load_state_dict(ckpt['network'], strict=True)
