@@ -99,6 +99,16 @@ int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, const fl
                      const float *W0, const float *b0, float *packed, float *xyz_out,
                      void *stream);
 
+/* bf16x3 variant of the non-rigid MLP (split-bf16 operands, fp32 accumulation; see
+ * occnerf_canonical_mlp_bf16x3).  packed = the fp32 blob (biases, folded layer-0 bias, output
+ * rows); packed_bf16 = occnerf_nonrigid_packed_bf16_bytes() zero-initialised bytes filled by
+ * occnerf_nonrigid_pack_bf16 from the first 6 weight pointers. */
+int64_t occnerf_nonrigid_packed_bf16_bytes(void);
+int occnerf_nonrigid_pack_bf16(const float *const *h_W, void *packed_bf16, void *stream);
+int occnerf_nonrigid_bf16x3(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
+                            const float *W0, const float *b0, float *packed, const void *packed_bf16,
+                            float *xyz_out, void *stream);
+
 /* Multi-scale exact kNN (k = 10, up to 4 point sets).  Replaces the pykeops
  * Kmin_argKmin reduction of knn.py:77-85 and the index bookkeeping of network.py:235-255.
  * points[M,3]: the scales concatenated (scale 0 = all base points first);

@@ -211,6 +211,225 @@ __global__ __launch_bounds__(256, 2) void nonrigid_kernel(const float *__restric
     }
 }
 
+
+// =======================================================================================
+// bf16x3 variant (see mlp.hip): hi/lo bf16 operands, Wh*xh + Wh*xl + Wl*xh, fp32 accumulate,
+// weights streamed once per workgroup through an LDS ring by LDS-DMA.  A 16 KiB chunk holds two
+// 16-wide k-steps x {hi,lo} x 4 output blocks; 23 chunks per tile.
+// =======================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kNrS_E = 3;                       // embedding: 18 slots per half -> 3 k-steps (6 pad)
+constexpr int kNrS_H = kNrW / 16;               // 8
+constexpr int kNrSteps = kNrS_E + 3 * kNrS_H + (kNrS_H + kNrS_E) + kNrS_H;   // 46
+static_assert(kNrSteps % 2 == 0, "two k-steps per chunk");
+constexpr int kNrChunks = kNrSteps / 2;
+constexpr int kNrChunkUnits = 1024;             // 16-byte units per chunk
+constexpr int kNrRing = 4;
+constexpr int kNrStepUnits = 2 * kNrOB * 64;    // [hi|lo][ob][lane]
+
+struct NrAux {      // floats in LDS
+    static constexpr int kL0B = 0, kHB = 128, kSkipB = 512, kL5B = 640, kOut = 768, kTotal = 1156;
+};
+
+__global__ void nr_pack_bf16_kernel(const float *__restrict__ W, int kind, int in_dim, int steps,
+                                    __bf16 *__restrict__ Wp) {
+    const int total = steps * 2 * kNrOB * 64 * 8;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int i = e & 7, lane = (e >> 3) & 63;
+        int rest = e >> 9;
+        const int ob = rest % kNrOB;
+        rest /= kNrOB;
+        const int which = rest & 1, step = rest >> 1;
+        const int col = nr_slot_feature(kind, step * 8 + i, lane >> 5);
+        const float w = col >= 0 ? W[(size_t)(ob * 32 + (lane & 31)) * in_dim + col] : 0.0f;
+        const __bf16 hi = (__bf16)w;
+        Wp[e] = which == 0 ? hi : (__bf16)(w - (float)hi);
+    }
+}
+
+struct NrSplit {
+    bf16x8 hi, lo;
+};
+
+__device__ __forceinline__ NrSplit nr_split8(const float (&v)[8]) {
+    NrSplit o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const __bf16 h = (__bf16)v[i];
+        o.hi[i] = h;
+        o.lo[i] = (__bf16)(v[i] - (float)h);
+    }
+    return o;
+}
+
+__device__ __forceinline__ void nr_glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+#define NR_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *__restrict__ xyz_in, int64_t N,
+                                                                 const float *__restrict__ pk,
+                                                                 const bf16x8 *__restrict__ pkh, NrParams prm,
+                                                                 float *__restrict__ xyz_out) {
+    __shared__ __attribute__((aligned(16))) bf16x8 smem[kNrRing * kNrChunkUnits + NrAux::kTotal / 4];
+    bf16x8 *ring = smem;
+    float *aux = reinterpret_cast<float *>(smem + kNrRing * kNrChunkUnits);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t n = ((int64_t)blockIdx.x * 4 + wave) * 32 + j;
+    const int64_t nsrc = n < N ? n : N - 1;
+
+    auto copy = [&](int dst, int64_t src, int count) {
+        for (int i = threadIdx.x; i < count; i += 256) aux[dst + i] = pk[src + i];
+    };
+    copy(NrAux::kL0B, NrBlob::kL0B, 128);
+    for (int l = 0; l < 3; l++) copy(NrAux::kHB + l * 128, NrBlob::kHW + l * NrBlob::kHStride + nr_wsz(kG_H), 128);
+    copy(NrAux::kSkipB, NrBlob::kSkipB, 128);
+    copy(NrAux::kL5B, NrBlob::kL5B, 128);
+    copy(NrAux::kOut, NrBlob::kOutW, 388);
+
+    const float p[3] = {xyz_in[nsrc * 3], xyz_in[nsrc * 3 + 1], xyz_in[nsrc * 3 + 2]};
+    NrSplit be[kNrS_E];      // embedding operands: slots 0..17 of this half, 6 zero pads
+    {
+        float e[24];
+#pragma unroll
+        for (int o = 0; o < 3; o++) {
+            const int oct = 3 * h + o;
+            const float freq = (float)(1 << oct);
+            const float wgt = oct == 0 ? prm.hann[0] : oct == 1 ? prm.hann[1] : oct == 2 ? prm.hann[2]
+                            : oct == 3 ? prm.hann[3] : oct == 4 ? prm.hann[4] : prm.hann[5];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float a = __fmul_rn(p[c], freq);
+                e[o * 6 + c] = __fmul_rn(wgt, sinf(a));
+                e[o * 6 + 3 + c] = __fmul_rn(wgt, cosf(a));
+            }
+        }
+#pragma unroll
+        for (int t = 18; t < 24; t++) e[t] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < kNrS_E; s++) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = e[s * 8 + i];
+            be[s] = nr_split8(v);
+        }
+    }
+    __syncthreads();
+
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) bf16x8 *)ring;
+    auto issue = [&](int g) {
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const int frag = wave * 4 + f;
+            nr_glds16(pkh + (size_t)g * kNrChunkUnits + frag * 64 + lane,
+                      ring_lds + (unsigned)(((g & (kNrRing - 1)) * kNrChunkUnits + frag * 64) * 16));
+        }
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+
+    // The k-steps of the whole network form one stream: step index `st` (compile-time after
+    // unrolling) -> chunk st/2, half st%2.  Entering a new chunk = counted wait + barrier + refill.
+    const bf16x8 *slot = ring;
+#define NR_STEP(ST, ACC, BSPLIT)                                                                   \
+    {                                                                                              \
+        if (((ST) & 1) == 0) {                                                                     \
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                       \
+            __builtin_amdgcn_s_barrier();                                                          \
+            issue((ST) / 2 + 3);                                                                   \
+            slot = ring + (((ST) / 2) & (kNrRing - 1)) * kNrChunkUnits;                            \
+        }                                                                                          \
+        const bf16x8 *st_ = slot + ((ST) & 1) * kNrStepUnits;                                      \
+        bf16x8 ah_[kNrOB], al_[kNrOB];                                                             \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ah_[ob_] = st_[ob_ * 64 + lane];   \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) al_[ob_] = st_[(kNrOB + ob_) * 64 + lane]; \
+        const NrSplit &b_ = (BSPLIT);                                                              \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ACC[ob_] = NR_MFMA_BF16(ah_[ob_], b_.hi, ACC[ob_]); \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ACC[ob_] = NR_MFMA_BF16(ah_[ob_], b_.lo, ACC[ob_]); \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ACC[ob_] = NR_MFMA_BF16(al_[ob_], b_.hi, ACC[ob_]); \
+    }
+#define NR_BIAS(OFF)                                                                               \
+    {                                                                                              \
+        const f32x4 *B4 = reinterpret_cast<const f32x4 *>(aux + (OFF));                            \
+        _Pragma("unroll") for (int ob = 0; ob < kNrOB; ob++) {                                     \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                        \
+                const f32x4 v = B4[(ob * 4 + q) * 2 + h];                                          \
+                _Pragma("unroll") for (int rr = 0; rr < 4; rr++) acc[ob][q * 4 + rr] = v[rr];      \
+            }                                                                                      \
+        }                                                                                          \
+    }
+#define NR_RELU_SPLIT()                                                                            \
+    _Pragma("unroll") for (int ob = 0; ob < kNrOB; ob++) {                                         \
+        _Pragma("unroll") for (int sub = 0; sub < 2; sub++) {                                      \
+            float v[8];                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 8; i++) v[i] = fmaxf(acc[ob][sub * 8 + i], 0.0f); \
+            bact[ob * 2 + sub] = nr_split8(v);                                                     \
+        }                                                                                          \
+    }
+
+    f32x16 acc[kNrOB];
+    NrSplit bact[2 * kNrOB];
+    // layer 0: embedding only (condition code folded into the bias): steps 0..2
+    NR_BIAS(NrAux::kL0B)
+#pragma unroll
+    for (int s = 0; s < kNrS_E; s++) NR_STEP(s, acc, be[s])
+    NR_RELU_SPLIT()
+    // layers 1..3: steps 3..26
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        NR_BIAS(NrAux::kHB + l * 128)
+#pragma unroll
+        for (int s = 0; s < kNrS_H; s++) NR_STEP(kNrS_E + l * kNrS_H + s, acc, bact[s])
+        NR_RELU_SPLIT()
+    }
+    // layer 4 (skip): [h(128), emb(36)]: steps 27..37
+    NR_BIAS(NrAux::kSkipB)
+#pragma unroll
+    for (int s = 0; s < kNrS_H; s++) NR_STEP(kNrS_E + 3 * kNrS_H + s, acc, bact[s])
+#pragma unroll
+    for (int s = 0; s < kNrS_E; s++) NR_STEP(kNrS_E + 4 * kNrS_H + s, acc, be[s])
+    NR_RELU_SPLIT()
+    // layer 5: steps 38..45
+    NR_BIAS(NrAux::kL5B)
+#pragma unroll
+    for (int s = 0; s < kNrS_H; s++) NR_STEP(2 * kNrS_E + 4 * kNrS_H + s, acc, bact[s])
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    float off[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const f32x4 *W4 = reinterpret_cast<const f32x4 *>(aux + NrAux::kOut + c * kNrW);
+        float sacc = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < kNrOB; kb++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 w = W4[(kb * 4 + q) * 2 + h];
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) sacc = __fmaf_rn(w[rr], fmaxf(acc[kb][q * 4 + rr], 0.0f), sacc);
+            }
+        }
+        off[c] = sacc + __shfl_xor(sacc, 32) + aux[NrAux::kOut + 3 * kNrW + c];
+    }
+    if (h == 0 && n < N) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) xyz_out[n * 3 + c] = __fadd_rn(p[c], off[c]);
+    }
+#undef NR_STEP
+#undef NR_BIAS
+#undef NR_RELU_SPLIT
+}
+
 }  // namespace occ
 
 OCC_API int64_t occnerf_nonrigid_packed_floats(void) { return occ::NrBlob::kTotal; }
@@ -235,6 +454,47 @@ OCC_API int occnerf_nonrigid_pack(const float *const *h_W, const float *const *h
     hipLaunchKernelGGL(nr_pack_rows_kernel, dim3(2), dim3(256), 0, st, h_W[6], h_b[6],
                        packed + NrBlob::kOutW, packed + NrBlob::kOutB);
     return check_launch("nonrigid_pack");
+}
+
+OCC_API int64_t occnerf_nonrigid_packed_bf16_bytes(void) {
+    return ((int64_t)occ::kNrChunks + occ::kNrRing - 1) * occ::kNrChunkUnits * 16;     // + read-ahead tail
+}
+
+OCC_API int occnerf_nonrigid_pack_bf16(const float *const *h_W, void *packed_bf16, void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(h_W && packed_bf16, "nonrigid_pack_bf16: null argument");
+    for (int i = 0; i < 6; i++) OCC_REQUIRE(h_W[i], "nonrigid_pack_bf16: layer %d missing", i);
+    hipStream_t st = as_stream(stream);
+    __bf16 *base = reinterpret_cast<__bf16 *>(packed_bf16);
+    int step = 0;
+    auto layer = [&](int li, int kind, int in_dim, int steps) {
+        hipLaunchKernelGGL(nr_pack_bf16_kernel, dim3(64), dim3(256), 0, st, h_W[li], kind, in_dim, steps,
+                           base + (size_t)step * kNrStepUnits * 8);
+        step += steps;
+    };
+    layer(0, kNrL0, kCond + kEmb, kNrS_E);
+    for (int l = 0; l < 3; l++) layer(1 + l, kNrHidden, kNrW, kNrS_H);
+    layer(4, kNrSkip, kNrW + kEmb, kNrS_H + kNrS_E);
+    layer(5, kNrHidden, kNrW, kNrS_H);
+    return check_launch("nonrigid_pack_bf16");
+}
+
+OCC_API int occnerf_nonrigid_bf16x3(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
+                                    const float *W0, const float *b0, float *packed, const void *packed_bf16,
+                                    float *xyz_out, void *stream) {
+    using namespace occ;
+    if (N <= 0) return 0;
+    OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && packed_bf16 && xyz_out,
+                "nonrigid_bf16x3: null argument");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(nr_fold_bias_kernel, dim3(1), dim3(128), 0, st, W0, b0, cond, packed + NrBlob::kL0B);
+    NrParams prm;
+    for (int i = 0; i < 6; i++) prm.hann[i] = h_hann[i];
+    const int64_t blocks = (N + 127) / 128;
+    OCC_REQUIRE(blocks < (1ll << 31), "nonrigid_bf16x3: N too large");
+    hipLaunchKernelGGL(nonrigid_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N, packed,
+                       reinterpret_cast<const bf16x8 *>(packed_bf16), prm, xyz_out);
+    return check_launch("nonrigid_bf16x3");
 }
 
 OCC_API int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,

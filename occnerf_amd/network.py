@@ -177,6 +177,8 @@ class Network(nn.Module):
             else None,
             'nr': ops.nonrigid_pack([m.weight.detach() for m in nr_lin],
                                     [m.bias.detach() for m in nr_lin]),
+            'nr_bf16': ops.nonrigid_pack_bf16([m.weight.detach() for m in nr_lin])
+            if self.cfg.get('mlp_precision', 'fp32') == 'bf16x3' else None,
             'nr_w0': nr_lin[0].weight.detach(), 'nr_b0': nr_lin[0].bias.detach(),
         }
         return self._packed
@@ -204,7 +206,10 @@ class Network(nn.Module):
                                           t_rand=t_rand)
         pk = self._packed_weights()
         if not cfg.ignore_non_rigid_motions:
-            xyz = ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
+            if pk['nr_bf16'] is not None:
+                xyz = ops.nonrigid_bf16x3(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'], out=xyz)
+            else:
+                xyz = ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
         if cfg.get('knn_culling', True):     # same results, ~5x fewer distance evaluations
             knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'])
         else:

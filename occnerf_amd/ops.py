@@ -162,6 +162,28 @@ def nonrigid(xyz, cond, hann, W0, b0, packed, out=None):
     return out
 
 
+def nonrigid_pack_bf16(weights):
+    dev = weights[0].device
+    n = _lib.lib().occnerf_nonrigid_packed_bf16_bytes()
+    packed = torch.zeros(n // 2, device=dev, dtype=torch.bfloat16)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_nonrigid_pack_bf16(_ptr_table(weights[:6], 'W'), packed.data_ptr(), _stream(packed))
+    _lib.check(rc, 'nonrigid_pack_bf16')
+    return packed
+
+
+def nonrigid_bf16x3(xyz, cond, hann, W0, b0, packed, packed_bf16, out=None):
+    out = torch.empty_like(xyz) if out is None else out
+    _kh, ph = _host_f32(hann, 6)
+    with _guard(xyz):
+        rc = _lib.lib().occnerf_nonrigid_bf16x3(
+            _chk(xyz, torch.float32, 'xyz'), xyz.shape[0], _chk(cond, torch.float32, 'cond'), ph,
+            _chk(W0, torch.float32, 'W0'), _chk(b0, torch.float32, 'b0'), _chk(packed, torch.float32, 'packed'),
+            _chk(packed_bf16, torch.bfloat16, 'packed_bf16'), _chk(out, torch.float32, 'xyz_out'), _stream(xyz))
+    _lib.check(rc, 'nonrigid_bf16x3')
+    return out
+
+
 def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
     N = xyz.shape[0]
     nscale = len(scale_begin) - 1

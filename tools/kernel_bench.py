@@ -27,6 +27,24 @@ def timeit(fn, n=3):
 torch.set_grad_enabled(False)
 
 
+def bench_nonrigid():
+    ctx = util.model_context(0, False)
+    W, B = util.nonrigid_params(ctx['sd'])
+    Wd = [torch.from_numpy(w).cuda() for w in W]
+    Bd = [torch.from_numpy(b).cuda() for b in B]
+    pk, ph = ops.nonrigid_pack(Wd, Bd), ops.nonrigid_pack_bf16(Wd)
+    N = 183784 * 128
+    xyz = (torch.rand(N, 3, device='cuda') - 0.5) * 2
+    cond = torch.randn(69, device='cuda') * 0.3
+    hann = np.ones(6, np.float32)
+    out = torch.empty_like(xyz)
+    t32 = timeit(lambda: ops.nonrigid(xyz, cond, hann, Wd[0], Bd[0], pk, out=out))
+    r32 = out.clone()
+    tb = timeit(lambda: ops.nonrigid_bf16x3(xyz, cond, hann, Wd[0], Bd[0], pk, ph, out=out))
+    print(f'nonrigid fp32   : {t32:8.2f} ms')
+    print(f'nonrigid bf16x3 : {tb:8.2f} ms   max|diff| = {float((out - r32).abs().max()):.3e}')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--samples', type=int, default=183784 * 128)
@@ -119,6 +137,9 @@ def bench_stage(name):
 
 
 if __name__ == '__main__':
+    if '--nonrigid' in sys.argv:
+        bench_nonrigid()
+        sys.exit(0)
     if '--stage' in sys.argv:
         bench_stage(sys.argv[sys.argv.index('--stage') + 1])
         sys.exit(0)
