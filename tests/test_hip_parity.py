@@ -369,10 +369,11 @@ def test_nonrigid(case, ops):
         got = ops.nonrigid(T(xyz), T(cond), hann, Wd[0], Bd[0], packed).cpu().numpy()
         want = orc.nonrigid(xyz, cond, hann, W, B)
         assert np.abs(got - want).max() <= 1e-6          # sinf/cosf + MFMA k-order vs libm/serial
-    # split-bf16 variant: offsets are <= ~1e-2 m, their 2^-17 relative split error is far below 1e-6
+    # split-bf16 variant: offsets are <= ~0.1 m (amplified checkpoint); 2^-17 relative split error per
+    # product through 7 layers -> a few 1e-6 m at most
     ph = ops.nonrigid_pack_bf16(Wd)
     gotb = ops.nonrigid_bf16x3(T(xyz), T(cond), np.ones(6, np.float32), Wd[0], Bd[0], packed, ph).cpu().numpy()
-    assert np.abs(gotb - orc.nonrigid(xyz, cond, np.ones(6, np.float32), W, B)).max() <= 1e-6
+    assert np.abs(gotb - orc.nonrigid(xyz, cond, np.ones(6, np.float32), W, B)).max() <= 5e-6
     if 'nr.xyz_out' in g:                                # what the reference's torch MLP returned
         got = ops.nonrigid(T(xyz), T(cond), np.ones(6, np.float32), Wd[0], Bd[0], packed).cpu().numpy()
         assert np.abs(got - g['nr.xyz_out']).max() <= 1e-6
