@@ -83,8 +83,8 @@ def main():
     from tests.gpu_util import build_network, frame_to_device
 
     net, ctx = build_network(seed=0, amplify=False, S=SPP, non_rigid=True, device=dev)
-    # each rank renders its own frame of the free-view orbit (frame 128 of 540 on rank 0)
-    frame = synth.make_frame(img_size=IMG, pose72=synth.seeded_pose(1), orbit_frame=28 + rank)
+    # every rank renders one full frame per step (the same free-view frame: identical work per GPU)
+    frame = synth.make_frame(img_size=IMG, pose72=synth.seeded_pose(1), orbit_frame=28)
     data = frame_to_device(frame, dev)
     R = frame['rays'].shape[1]
 
@@ -105,14 +105,9 @@ def main():
         with torch.no_grad():
             out = net(**data, iter_val=1e7)
         packed = torch.cat([out['rgb'], out['alpha'][:, None], out['depth'][:, None]], dim=1)
-        if world > 1:                                  # shards of different frames differ in size
-            sizes = [torch.zeros(1, dtype=torch.long, device=dev) for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([packed.shape[0]], device=dev))
-            width = int(max(int(s) for s in sizes))
-            pad = packed.new_zeros(width, 5)
-            pad[:packed.shape[0]] = packed
-            bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-            dist.gather(pad, bufs, dst=0)
+        if world > 1:                                  # the path's one exchange step: [R,5] to rank 0
+            bufs = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
+            dist.gather(packed, bufs, dst=0)
         return packed
 
     for _ in range(args.warmup):
