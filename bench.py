@@ -58,6 +58,19 @@ def cpu_baseline(ctx, frame, n_rays):
                       f'oracle/occnerf_oracle.c (OpenMP), {dt:.1f} s'}
 
 
+def pmc_traffic(n_samples):
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 cannot run
+    inside this process); only quoted when it was collected at the same launch size."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')
+    try:
+        d = json.load(open(path))
+        if int(d['samples_per_launch']) == int(n_samples):
+            return float(d['kernels']['occ::canonical_mlp_kernel']['hbm_bytes_corrected'])
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -171,7 +184,9 @@ def main():
                        'parallelism': f'frames x{world} (rays sharded by frame), RCCL gather to rank 0'},
             'roofline': {'bound': 'mfma', 'kernel': 'occ::canonical_mlp_kernel (fp32 MFMA 32x32x2)',
                          'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA, 'traffic': None,
+                         'frac': achieved / PEAK_FP32_MFMA, 'traffic': pmc_traffic(float(np.mean(nsmp))),
+                         'traffic_note': 'HBM bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_hbm.json; '
+                                         'algorithmic 288 B/sample',
                          'launch_ms': avg_ms, 'launches_timed': len(ms),
                          'flop_per_launch': FLOP_PER_SAMPLE_CNL * float(np.mean(nsmp))},
         }
