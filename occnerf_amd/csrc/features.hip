@@ -268,6 +268,210 @@ __global__ __launch_bounds__(256) void sample_features_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// sample_features, 8 lanes per sample.  The thread-per-sample kernel above keeps the memory
+// pipeline (TA) 98 % busy with ~700 line look-ups per sample, one per lane per instruction, and
+// writes its 272-byte rows in partial lines (3x write amplification, profiles/r01_pmc_hbm.json).
+// Here a sample is owned by 8 consecutive lanes:
+//   * a table row's 32 encoding features are one float4 per lane = 128 contiguous bytes (2 line
+//     look-ups instead of 8), the 3-float tail goes to lane j & 7;
+//   * lane g encodes hash levels 2g and 2g+1 and ends up holding exactly the float4 it stores;
+//   * the 10 finest neighbours are spread over the lanes and combined in the reference's
+//     sequential order through shuffles, so the encoder input stays bit-identical to the oracle;
+//   * outputs are written as 128-byte (8 x float4) runs.
+// Used for the renderer's normal call (4 scales, counters gathered through knn_idxs).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float grp_sum8(float v) {
+    v += __shfl_xor(v, 1, 8);
+    v += __shfl_xor(v, 2, 8);
+    v += __shfl_xor(v, 4, 8);
+    return v;
+}
+__device__ __forceinline__ float grp_min8(float v) {
+    v = fminf(v, __shfl_xor(v, 1, 8));
+    v = fminf(v, __shfl_xor(v, 2, 8));
+    return fminf(v, __shfl_xor(v, 4, 8));
+}
+__device__ __forceinline__ float grp_max8(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 8));
+    v = fmaxf(v, __shfl_xor(v, 2, 8));
+    return fmaxf(v, __shfl_xor(v, 4, 8));
+}
+
+__global__ __launch_bounds__(256, 4) void sample_features8_kernel(
+    const float *__restrict__ xyz, int64_t N, const int32_t *__restrict__ knn_idxs,
+    const float *__restrict__ point_base, const double *__restrict__ normals,
+    const double *__restrict__ unit, const float *__restrict__ counter,
+    const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
+    const int32_t *__restrict__ offsets, GridLevels lv, GridModes4 gm, FeatParams prm,
+    float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
+    constexpr int NK = 4 * kKnn;                       // 40 neighbours over 4 scales
+    const int g = threadIdx.x & 7;
+    const int64_t group0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> 3;
+    const int64_t iters = (N + ngroups - 1) / ngroups;
+    for (int64_t it = 0; it < iters; it++) {
+        const int64_t i_raw = group0 + it * ngroups;
+        const bool live = i_raw < N;
+        const int64_t i = live ? i_raw : N - 1;         // keep every lane in the shuffles
+        const int32_t *id = knn_idxs + i * NK;
+        const float p[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+
+        // ---- neighbour geometry: lane g owns neighbour g, lanes 0/1 also 8/9 ----
+        float nrm[2];
+        int negf[2];
+        double t_att = 0.0, t_num[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int jn = a == 0 ? g : 8 + (g & 1);
+            const int n = id[jn];
+            float dir[3], nbr[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                nbr[c] = point_base[n * 3 + c];
+                dir[c] = __fsub_rn(p[c], nbr[c]);
+            }
+            double dot = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) dot = __dadd_rn(dot, __dmul_rn((double)dir[c], normals[(size_t)n * 3 + c]));
+            negf[a] = dot < 0.0;
+            nrm[a] = norm3(dir[0], dir[1], dir[2]);
+            if (a == 0) {      // only neighbours 0..2 are used below; computed by every lane (uniform code)
+                t_att = fabs(cos3_unit(dir, unit + (size_t)n * 3));
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float pn = __fdiv_rn(__fadd_rn(nbr[c], prm.bound), prm.two_bound);
+                    t_num[c] = __dmul_rn(t_att, (double)pn);
+                }
+            }
+        }
+        // sequential combination in neighbour order j = 0..9 (fp32 sum) / 0..2 (fp64 sums)
+        float dsum = 0.0f;
+        int neg = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            dsum = __fadd_rn(dsum, __shfl(nrm[0], j, 8));
+            neg += __shfl(negf[0], j, 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            dsum = __fadd_rn(dsum, __shfl(nrm[1], j, 8));
+            neg += __shfl(negf[1], j, 8);
+        }
+        double num[3] = {0.0, 0.0, 0.0}, den = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) num[c] = __dadd_rn(num[c], __shfl(t_num[c], j, 8));
+            den = __dadd_rn(den, __shfl(t_att, j, 8));
+        }
+        float dist = __fdiv_rn(dsum, (float)kKnn);
+        if (2 * neg > kKnn) dist = -dist;
+        float nd = __fdiv_rn(__fadd_rn(dist, 0.2f), 0.5f);
+        nd = nd < 0.0f ? 0.0f : (nd > 1.0f ? 1.0f : nd);
+        float x[4];
+#pragma unroll
+        for (int c = 0; c < 3; c++) x[c] = (float)__ddiv_rn(num[c], den);
+        x[3] = nd;
+        float *out = mlp_in + i * 68;
+        if (live && g == 0) {
+            raw[i * 5 + 4] = dist;
+            if (enc_in_out) *reinterpret_cast<float4 *>(enc_in_out + i * 4) = make_float4(x[0], x[1], x[2], x[3]);
+        }
+
+        // ---- hash encoding: lane g -> levels 2g, 2g+1 -> features 4g..4g+3 ----
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 4; d++) oob |= (x[d] < 0.f || x[d] > 1.f);
+        float2 ev[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+        if (!oob) {
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const int l = 2 * g + a;
+                const uint32_t o0 = (uint32_t)offsets[l];
+                ev[a] = encode_level_d4c2(x, embeddings + o0, (uint32_t)offsets[l + 1] - o0, lv.scale[l],
+                                          lv.resolution[l], gm.mode[l]);
+            }
+        }
+        if (live) *reinterpret_cast<float4 *>(out + 36 + 4 * g) = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);
+
+        // ---- visibility softmax: lane g owns neighbours 5g..5g+4 ----
+        int id5[5];
+        float a5[5];
+        float lmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            id5[k] = id[g * 5 + k];
+            a5[k] = counter[id5[k]];
+            lmin = fminf(lmin, a5[k]);
+        }
+        const float amin = grp_min8(lmin);
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            a5[k] = __fadd_rn(a5[k], __fsub_rn(1.0f, amin));
+            lmax = fmaxf(lmax, a5[k]);
+        }
+        const float amax = grp_max8(lmax);
+        float lsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            a5[k] = __fdiv_rn(a5[k], amax);
+            lsum += a5[k];
+        }
+        const float mean = __fdiv_rn(grp_sum8(lsum), (float)NK);
+        float lvar = 0.0f, lsm = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float dl = a5[k] - mean;
+            lvar += dl * dl;
+            lsm = fmaxf(lsm, a5[k]);
+        }
+        const float var = __fdiv_rn(grp_sum8(lvar), (float)(NK - 1));
+        const float smax = grp_max8(lsm);
+        float le = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            a5[k] = expf(__fsub_rn(a5[k], smax));
+            le += a5[k];
+        }
+        const float ssum = grp_sum8(le);
+#pragma unroll
+        for (int k = 0; k < 5; k++) a5[k] = __fdiv_rn(a5[k], ssum);
+
+        // ---- gather the 40 rows: 128 B of encoding per row across the 8 lanes, tail on lane j&7 ----
+        float agg[4] = {0.f, 0.f, 0.f, 0.f}, tail[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int o = 0; o < 8; o++) {                   // owner lane of neighbours 5o..5o+4
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int j = o * 5 + k;
+                const int rowid = __shfl(id5[k], o, 8);
+                const float w = __shfl(a5[k], o, 8);
+                const float4 *row = table + (size_t)rowid * (kTableStride / 4);
+                const float4 t = row[g];
+                agg[0] = __fadd_rn(agg[0], __fmul_rn(w, t.x));
+                agg[1] = __fadd_rn(agg[1], __fmul_rn(w, t.y));
+                agg[2] = __fadd_rn(agg[2], __fmul_rn(w, t.z));
+                agg[3] = __fadd_rn(agg[3], __fmul_rn(w, t.w));
+                if (g == (j & 7)) {
+                    const float4 tt = row[8];
+                    tail[0] += w * tt.x;
+                    tail[1] += w * tt.y;
+                    tail[2] += w * tt.z;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) tail[c] = grp_sum8(tail[c]);
+        if (live) {
+            *reinterpret_cast<float4 *>(out + 4 * g) = make_float4(agg[0], agg[1], agg[2], agg[3]);
+            if (g == 0) *reinterpret_cast<float4 *>(out + 32) = make_float4(tail[0], tail[1], tail[2], var);
+        }
+    }
+}
+
 }  // namespace occ
 
 // The unit normals are a per-model constant; they are cached in a small device buffer
@@ -329,6 +533,15 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
     const GridLevels lv = make_grid_levels(L, S, H);
     const GridModes4 gm = modes_from_host_offsets(L, lv, h_offsets);
     FeatParams prm{bound, two_bound, nscale, (int)L};
+    if (nscale == 4 && !geo_idxs && !att_in && counter) {      // the renderer's call: 8 lanes per sample
+        int64_t blocks8 = (N + 31) / 32;
+        if (blocks8 > (int64_t)kNumCU * 32) blocks8 = (int64_t)kNumCU * 32;
+        hipLaunchKernelGGL(sample_features8_kernel, dim3((unsigned)blocks8), dim3(256), 0, as_stream(stream), xyz,
+                           N, knn_idxs, point_base, normals, unit_normals, counter,
+                           reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),
+                           offsets, lv, gm, prm, mlp_in, raw, enc_in);
+        return check_launch("sample_features");
+    }
     int64_t blocks = (N + 255) / 256;
     if (blocks > (int64_t)kNumCU * 16) blocks = (int64_t)kNumCU * 16;
     hipLaunchKernelGGL(sample_features_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, N,
