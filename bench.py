@@ -12,7 +12,7 @@ reference's module seam) with the frame's inputs already resident in HBM, then g
 shard by frame across ranks: per-GPU work is fixed as N grows (weak scaling); `value` is
 rays of all ranks / wall time (max over ranks).  Rank 0 prints ONE JSON line.
 
-`roofline`: the dominant kernel is the fp32-MFMA canonical MLP (occnerf_amd/csrc/mlp.hip).
+`roofline`: the dominant kernel is the fp32-MFMA canonical MLP (occnerf_amd/csrc/mlp16.hip).
 achieved = 923 136 FLOP/sample x samples per launch / average launch duration, measured
 with HIP events recorded on the launch stream around every launch inside the timed region.
 `cpu_baseline`: the CPU oracle (a port of the reference path, OpenMP on all host cores of
@@ -65,7 +65,8 @@ def pmc_traffic(n_samples):
     try:
         d = json.load(open(path))
         if int(d['samples_per_launch']) == int(n_samples):
-            return float(d['kernels']['occ::canonical_mlp_kernel']['hbm_bytes_corrected'])
+            k = d['kernels']
+            return float((k.get('occ::m16::canonical_mlp_lds_kernel') or k['occ::canonical_mlp_kernel'])['hbm_bytes_corrected'])
     except Exception:
         pass
     return None
@@ -182,7 +183,7 @@ def main():
                                    f'and camera; {R} rays hit the body bbox (ray_mask), one frame per GPU per step',
                        'rays_per_frame': R, 'samples_per_ray': SPP, 'image': [IMG, IMG],
                        'parallelism': f'frames x{world} (rays sharded by frame), RCCL gather to rank 0'},
-            'roofline': {'bound': 'mfma', 'kernel': 'occ::canonical_mlp_kernel (fp32 MFMA 32x32x2)',
+            'roofline': {'bound': 'mfma', 'kernel': 'occ::m16::canonical_mlp_lds_kernel (fp32 MFMA 16x16x4, LDS-staged weights)',
                          'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA, 'traffic': pmc_traffic(float(np.mean(nsmp))),
                          'traffic_note': 'HBM bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_hbm.json; '

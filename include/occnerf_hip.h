@@ -197,9 +197,15 @@ int occnerf_canonical_mlp_pack(const float *const *h_W, const float *const *h_b,
                                void *stream);
 
 /* Geometry + colour trunks on fp32 MFMA.  Replaces occnerf_mlp.py:183-199.
- * mlp_in[N,68] -> raw[N,5] columns 0..3 (rgb logits, sigma); column 4 is left alone. */
+ * mlp_in[N,68] -> raw[N,5] columns 0..3 (rgb logits, sigma); column 4 is left alone.
+ * occnerf_canonical_mlp: 16-sample waves (v_mfma_f32_16x16x4_f32), weights staged through LDS -- the
+ * default.  occnerf_canonical_mlp_direct: 32-sample waves (32x32x2), weights straight from L2; same
+ * packed buffer, same results to fp32 rounding (the dot products associate differently), kept as the
+ * cross-check and for A/B timing. */
 int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *packed, float *raw,
                           void *stream);
+int occnerf_canonical_mlp_direct(const float *mlp_in, int64_t N, const float *packed, float *raw,
+                                 void *stream);
 
 /* The same two trunks on the bf16 matrix pipe with split operands ("bf16x3"): every fp32
  * weight and activation is carried as hi + lo bf16 (16 significand bits) and each product is

@@ -42,6 +42,7 @@ SIGNATURES = {
     'occnerf_canonical_mlp_packed_floats': (_i64, []),
     'occnerf_canonical_mlp_pack': (C.c_int, [_vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    'occnerf_canonical_mlp_direct': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     'occnerf_canonical_mlp_packed_bf16_bytes': (_i64, []),
     'occnerf_canonical_mlp_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_canonical_mlp_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp]),

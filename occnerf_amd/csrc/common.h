@@ -153,4 +153,10 @@ __device__ __forceinline__ float norm3(float x, float y, float z) {
     return sqrtf(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
 }
 
+// LDS-staged fp32 canonical MLP (mlp16.hip); its packed stream sits behind the Blob of mlp.hip in the
+// buffer occnerf_canonical_mlp_pack fills.
+int64_t mlp_lds_packed_floats();
+int mlp_lds_pack(const float *const *h_W, const float *const *h_b, float *packed, hipStream_t st);
+int mlp_lds_launch(const float *mlp_in, int64_t N, const float *packed, float *raw, hipStream_t st);
+
 }  // namespace occ

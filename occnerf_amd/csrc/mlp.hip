@@ -1,4 +1,6 @@
-// Canonical density/colour MLP on fp32 MFMA:
+// Canonical density/colour MLP on fp32 MFMA -- the 32-sample-per-wave,
+// direct-load kernel (occnerf_canonical_mlp_direct; the default is the LDS-staged kernel in mlp16.hip)
+// and the split-bf16 variants:
 //   geometry trunk  68 -> 256 -> 256 -> 256 -> 256 -> 65   (sigma = row 0)
 //   colour trunk   131 -> 256 -> 256 -> 256 -> 256 -> 3
 // occnerf_mlp.py:183-199, 461 568 MAC = 923 136 FLOP per sample -- the dominant
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
 
 }  // namespace occ
 
-OCC_API int64_t occnerf_canonical_mlp_packed_floats(void) { return occ::Blob::kTotal; }
+OCC_API int64_t occnerf_canonical_mlp_packed_floats(void) { return occ::Blob::kTotal + occ::mlp_lds_packed_floats(); }
 
 OCC_API int occnerf_canonical_mlp_pack(const float *const *h_W, const float *const *h_b,
                                        float *packed, void *stream) {
@@ -743,7 +745,8 @@ OCC_API int occnerf_canonical_mlp_pack(const float *const *h_W, const float *con
     }
     hipLaunchKernelGGL(pack_rows_kernel, dim3(4), dim3(256), 0, st, h_W[9], h_b[9], 3,
                        packed + Blob::kOutW, packed + Blob::kOutB);
-    return check_launch("canonical_mlp_pack");
+    if (int rc = check_launch("canonical_mlp_pack")) return rc;
+    return mlp_lds_pack(h_W, h_b, packed + Blob::kTotal, st);
 }
 
 OCC_API int64_t occnerf_canonical_mlp_packed_bf16_bytes(void) {
@@ -791,10 +794,17 @@ OCC_API int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *p
     using namespace occ;
     if (N <= 0) return 0;
     OCC_REQUIRE(mlp_in && packed && raw, "canonical_mlp: null argument");
+    return mlp_lds_launch(mlp_in, N, packed + Blob::kTotal, raw, as_stream(stream));
+}
+
+OCC_API int occnerf_canonical_mlp_direct(const float *mlp_in, int64_t N, const float *packed, float *raw,
+                                         void *stream) {
+    using namespace occ;
     if (N <= 0) return 0;
+    OCC_REQUIRE(mlp_in && packed && raw, "canonical_mlp_direct: null argument");
     const int64_t blocks = (N + 127) / 128;
-    OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp: N too large");
+    OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_direct: N too large");
     hipLaunchKernelGGL(canonical_mlp_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                        mlp_in, N, packed, raw);
-    return check_launch("canonical_mlp");
+    return check_launch("canonical_mlp_direct");
 }

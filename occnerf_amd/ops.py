@@ -297,11 +297,12 @@ def canonical_mlp_pack(weights, biases):
     return packed
 
 
-def canonical_mlp(mlp_in, packed, raw):
+def canonical_mlp(mlp_in, packed, raw, direct=False):
+    """fp32 MLP trunks.  direct=True: the 32-sample-wave direct-load kernel (cross-check / A-B timing)."""
+    fn = _lib.lib().occnerf_canonical_mlp_direct if direct else _lib.lib().occnerf_canonical_mlp
     with _guard(mlp_in):
-        rc = _lib.lib().occnerf_canonical_mlp(_chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0],
-                                              _chk(packed, torch.float32, 'packed'),
-                                              _chk(raw, torch.float32, 'raw'), _stream(mlp_in))
+        rc = fn(_chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0], _chk(packed, torch.float32, 'packed'),
+                _chk(raw, torch.float32, 'raw'), _stream(mlp_in))
     _lib.check(rc, 'canonical_mlp')
     return raw
 

@@ -311,6 +311,26 @@ def test_sample_features_and_mlp(case, ops):
     from tests.test_oracle_golden import _mlp_f64
     ref = _mlp_f64(o['mlp_in'], Wg, Bg, Wc, Bc)
     assert np.abs(raw2.cpu().numpy()[:, :4] - ref).max() <= (5e-5 if amp else 1e-6)
+    # the 32-sample-wave direct-load kernel: same packed buffer, same bound
+    raw3 = torch.zeros_like(raw)
+    ops.canonical_mlp(T(o['mlp_in']), packed, raw3, direct=True)
+    assert np.abs(raw3.cpu().numpy()[:, :4] - ref).max() <= (5e-5 if amp else 1e-6)
+
+
+@pytest.mark.parametrize('n', [1, 15, 16, 17, 63, 64, 65, 1000, 4097])
+def test_canonical_mlp_ragged(ops, n):
+    """Workgroups of 4 waves x 16 samples: partial waves, partial workgroups, column 4 untouched."""
+    ctx = util.model_context(0, False)
+    Wg, Bg, Wc, Bc = util.canonical_mlp_params(ctx['sd'])
+    packed = ops.canonical_mlp_pack([T(w) for w in Wg + Wc], [T(b) for b in Bg + Bc])
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal((n, 68)) * 0.3).astype(np.float32)
+    raw = torch.full((n + 3, 5), 7.0, device=DEV)             # 3 guard rows behind the batch
+    ops.canonical_mlp(T(x), packed, raw[:n])
+    from tests.test_oracle_golden import _mlp_f64
+    got = raw.cpu().numpy()
+    assert np.abs(got[:n, :4] - _mlp_f64(x, Wg, Bg, Wc, Bc)).max() <= 1e-6
+    assert (got[:n, 4] == 7.0).all() and (got[n:] == 7.0).all()
 
 
 def test_canonical_mlp_bf16x3(case, ops):

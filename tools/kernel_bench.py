@@ -62,6 +62,9 @@ def main():
     r32 = raw.clone()
     flop = 923136.0 * N
     print(f'canonical_mlp fp32          : {t32:8.2f} ms  {flop / t32 / 1e9:8.1f} TFLOP/s')
+    td = timeit(lambda: ops.canonical_mlp(mlp_in, packed, raw, direct=True))
+    print(f'canonical_mlp fp32 direct   : {td:8.2f} ms  {flop / td / 1e9:8.1f} TFLOP/s  '
+          f'max|diff vs default| = {float((raw[:, :4] - r32[:, :4]).abs().max()):.3e}')
     for variant, name in ((1, 'direct'), (0, 'lds   ')):
         tb = timeit(lambda: ops.canonical_mlp_bf16x3(mlp_in, packed, packed_h, raw, variant=variant))
         print(f'canonical_mlp bf16x3 {name} : {tb:8.2f} ms  {flop / tb / 1e9:8.1f} TFLOP/s (algorithmic)  '
