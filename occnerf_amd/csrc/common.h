@@ -37,6 +37,13 @@ inline int check_launch(const char *what) {
         }                              \
     } while (0)
 
+// Load through a wave-uniform base pointer and a 32-bit byte offset.  hipcc then emits the
+// SGPR-base form of global_load (address payload 4 B per lane instead of 8); only for tables < 4 GiB.
+template <typename T>
+__device__ __forceinline__ T ld32(const T *base, uint32_t byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 // ---- multi-resolution grid: per-level constants computed on the HOST so that device
 // exp2f accuracy never enters the result (oracle: oc_grid_level_params) ---------------
 constexpr int kMaxLevels = 16;
@@ -90,9 +97,11 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align_cor
 // oc_grid_encode_one and with gridencoder.cu:137-199.  `grid` points at this level's slice.
 // The corner weights ((1*a0)*a1)*a2)*a3 are formed through shared partial products (identical
 // roundings, 28 instead of 48 multiplies) and the index through per-axis partial terms.
+// `grid` + entry0 is this level's slice: with a wave-uniform `grid` (the whole table) and a per-lane
+// 32-bit entry0 the gathers take the SGPR-base + 32-bit-offset form of global_load.
 __device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const float2 *grid,
                                                     uint32_t hashmap_size, float scale,
-                                                    uint32_t resolution, uint32_t mode) {
+                                                    uint32_t resolution, uint32_t mode, uint32_t entry0 = 0) {
     float f[4][2];        // per axis: weight of the lower / upper cell
     uint32_t pg[4];
 #pragma unroll
@@ -139,7 +148,7 @@ __device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const f
             const uint32_t pl[4] = {pg[0] + b0, pg[1] + b1, pg[2] + b2, pg[3] + b3};
             index = grid_index<4>(0, false, hashmap_size, resolution, pl);
         }
-        const float2 v = grid[index];
+        const float2 v = ld32(grid, (entry0 + index) * 8u);
         r.x = __fmaf_rn(w, v.x, r.x);
         r.y = __fmaf_rn(w, v.y, r.y);
     }

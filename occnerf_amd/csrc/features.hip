@@ -329,12 +329,12 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
             float dir[3], nbr[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                nbr[c] = point_base[n * 3 + c];
+                nbr[c] = ld32(point_base, (uint32_t)n * 12u + (uint32_t)c * 4u);
                 dir[c] = __fsub_rn(p[c], nbr[c]);
             }
             double dot = 0.0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) dot = __dadd_rn(dot, __dmul_rn((double)dir[c], normals[(size_t)n * 3 + c]));
+            for (int c = 0; c < 3; c++) dot = __dadd_rn(dot, __dmul_rn((double)dir[c], ld32(normals, (uint32_t)n * 24u + (uint32_t)c * 8u)));
             negf[a] = dot < 0.0;
             nrm[a] = norm3(dir[0], dir[1], dir[2]);
             if (a == 0) {      // only neighbours 0..2 are used below; computed by every lane (uniform code)
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
             for (int a = 0; a < 2; a++) {
                 const int l = 2 * g + a;
                 const uint32_t o0 = (uint32_t)offsets[l];
-                ev[a] = encode_level_d4c2(x, embeddings + o0, (uint32_t)offsets[l + 1] - o0, lv.scale[l],
-                                          lv.resolution[l], gm.mode[l]);
+                ev[a] = encode_level_d4c2(x, embeddings, (uint32_t)offsets[l + 1] - o0, lv.scale[l],
+                                          lv.resolution[l], gm.mode[l], o0);
             }
         }
         if (live) *reinterpret_cast<float4 *>(out + 36 + 4 * g) = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             id5[k] = id[g * 5 + k];
-            a5[k] = counter[id5[k]];
+            a5[k] = ld32(counter, (uint32_t)id5[k] * 4u);
             lmin = fminf(lmin, a5[k]);
         }
         const float amin = grp_min8(lmin);
@@ -449,14 +449,14 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
                 const int j = o * 5 + k;
                 const int rowid = __shfl(id5[k], o, 8);
                 const float w = __shfl(a5[k], o, 8);
-                const float4 *row = table + (size_t)rowid * (kTableStride / 4);
-                const float4 t = row[g];
+                const uint32_t row = (uint32_t)rowid * (uint32_t)(kTableStride * 4);      // byte offset of the row
+                const float4 t = ld32(table, row + (uint32_t)g * 16u);
                 agg[0] = __fadd_rn(agg[0], __fmul_rn(w, t.x));
                 agg[1] = __fadd_rn(agg[1], __fmul_rn(w, t.y));
                 agg[2] = __fadd_rn(agg[2], __fmul_rn(w, t.z));
                 agg[3] = __fadd_rn(agg[3], __fmul_rn(w, t.w));
                 if (g == (j & 7)) {
-                    const float4 tt = row[8];
+                    const float4 tt = ld32(table, row + 128u);
                     tail[0] += w * tt.x;
                     tail[1] += w * tt.y;
                     tail[2] += w * tt.z;

@@ -104,22 +104,32 @@ __device__ __forceinline__ void nr_load_bias(f32x16 (&acc)[kNrOB], const float *
     for (int ob = 0; ob < kNrOB; ob++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const f32x4 v = B4[(ob * 4 + q) * 2 + h];
+            const f32x4 v = ld32(B4, (uint32_t)(((ob * 4 + q) * 2 + h) * 16));
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) acc[ob][q * 4 + rr] = v[rr];
         }
     }
 }
 
-#define NR_LAYER(GROUPS, W4PTR, ACC, BOP)                                                     \
+// Weight loads are buffer loads: SGPR descriptor of the packed blob + 32-bit lane offset + scalar layer
+// offset.  A global_load whose address is a 64-bit VGPR pair per lane costs the issuing SIMD ~40 cycles of
+// matrix-pipe time per instruction on gfx950 (measured on the canonical MLP).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 nr_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// W_OFF: byte offset of the layer's weights inside the packed blob (wave-uniform)
+#define NR_LAYER(GROUPS, W_OFF, ACC, BOP)                                                     \
     {                                                                                         \
-        const f32x4 *w4_ = (W4PTR);                                                           \
+        const unsigned w_off_ = (unsigned)(W_OFF);                                            \
         f32x4 wc_[kNrOB], wn_[kNrOB];                                                         \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) wc_[ob_] = w4_[ob_ * 64 + lane]; \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++)                               \
+            wc_[ob_] = nr_bload(rsrc, lane16 + ob_ * 1024, w_off_);                           \
         _Pragma("unroll") for (int g_ = 0; g_ < (GROUPS); g_++) {                             \
             if (g_ + 1 < (GROUPS)) {                                                          \
                 _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++)                       \
-                    wn_[ob_] = w4_[((g_ + 1) * kNrOB + ob_) * 64 + lane];                     \
+                    wn_[ob_] = nr_bload(rsrc, lane16 + ((g_ + 1) * kNrOB + ob_) * 1024, w_off_); \
             }                                                                                 \
             _Pragma("unroll") for (int rr_ = 0; rr_ < 4; rr_++) {                             \
                 const int t_ = g_ * 4 + rr_;                                                  \
@@ -144,6 +154,9 @@ __global__ __launch_bounds__(256, 2) void nonrigid_kernel(const float *__restric
     const int64_t n = tile * 32 + j;
     const int64_t nsrc = n < N ? n : N - 1;
     const float p[3] = {xyz_in[nsrc * 3], xyz_in[nsrc * 3 + 1], xyz_in[nsrc * 3 + 2]};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(pk), 0, (int)(NrBlob::kTotal * sizeof(float)), 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
 
     // embedding feature f = octave*6 + {sin: 0..2, cos: 3..5}; this half-wave holds features
     // h*18 .. h*18+17, i.e. octaves 3h .. 3h+2
@@ -173,20 +186,20 @@ __global__ __launch_bounds__(256, 2) void nonrigid_kernel(const float *__restric
         _Pragma("unroll") for (int r = 0; r < 16; r++) act[ob][r] = fmaxf(acc[ob][r], 0.0f); \
     }
     nr_load_bias(acc, pk + NrBlob::kL0B, h);
-    NR_LAYER(kG_E, reinterpret_cast<const f32x4 *>(pk + NrBlob::kL0W), acc, BOP_E)
+    NR_LAYER(kG_E, NrBlob::kL0W * 4, acc, BOP_E)
     NR_RELU()
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
         const float *base = pk + NrBlob::kHW + l * NrBlob::kHStride;
         nr_load_bias(acc, base + nr_wsz(kG_H), h);
-        NR_LAYER(kG_H, reinterpret_cast<const f32x4 *>(base), acc, BOP_A)
+        NR_LAYER(kG_H, (NrBlob::kHW + l * NrBlob::kHStride) * 4, acc, BOP_A)
         NR_RELU()
     }
     nr_load_bias(acc, pk + NrBlob::kSkipB, h);
-    NR_LAYER(kG_H + kG_E, reinterpret_cast<const f32x4 *>(pk + NrBlob::kSkipW), acc, BOP_SKIP)
+    NR_LAYER(kG_H + kG_E, NrBlob::kSkipW * 4, acc, BOP_SKIP)
     NR_RELU()
     nr_load_bias(acc, pk + NrBlob::kL5B, h);
-    NR_LAYER(kG_H, reinterpret_cast<const f32x4 *>(pk + NrBlob::kL5W), acc, BOP_A)
+    NR_LAYER(kG_H, NrBlob::kL5W * 4, acc, BOP_A)
     NR_RELU()
 
     float off[3];
@@ -263,12 +276,15 @@ __device__ __forceinline__ NrSplit nr_split8(const float (&v)[8]) {
     return o;
 }
 
-__device__ __forceinline__ void nr_glds16(const void *gsrc, unsigned lds_dst) {
+// LDS-DMA of 64 x 16 B: wave-uniform source base (SGPR pair) + 32-bit lane offset ("saddr" form -- a
+// 64-bit VGPR address per lane costs the issuing SIMD ~40 cycles of matrix-pipe time per instruction on
+// gfx950), wave-uniform LDS destination in M0 (lane i lands at +16 i).
+__device__ __forceinline__ void nr_glds16(const void *gbase, unsigned lane_off, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
+                 : "v"(lane_off), "s"(gbase), "s"(lds_dst)
                  : "memory");
 }
 
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *__
 #pragma unroll
         for (int f = 0; f < 4; f++) {
             const int frag = wave * 4 + f;
-            nr_glds16(pkh + (size_t)g * kNrChunkUnits + frag * 64 + lane,
+            nr_glds16(pkh + (size_t)g * kNrChunkUnits + frag * 64, lane * 16,
                       ring_lds + (unsigned)(((g & (kNrRing - 1)) * kNrChunkUnits + frag * 64) * 16));
         }
     };
