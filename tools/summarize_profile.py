@@ -49,7 +49,7 @@ def main():
         name = r['Name']
         out.append(f"| `{name[:64]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | "
                    f"{float(r['MinNs']) / 1e6:.3f} | {float(r['MaxNs']) / 1e6:.3f} | {float(r['Percentage']):.2f} |")
-        if name.startswith('occ::canonical_mlp_kernel'):
+        if name.startswith('occ::m16::canonical_mlp_lds_kernel'):
             mlp = r
     out.append('')
     if mlp is not None and line is not None:
@@ -58,15 +58,15 @@ def main():
         trace = sorted(glob.glob(os.path.join(args.prof_dir, '**', '*kernel_trace.csv'), recursive=True))
         if trace:                       # the timed region = the launches after the warm-up steps
             d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9 for r in csv.DictReader(open(trace[0]))
-                 if r['Kernel_Name'].startswith('occ::canonical_mlp_kernel')]
+                 if r['Kernel_Name'].startswith('occ::m16::canonical_mlp_lds_kernel')]
             timed = d[line['warmup']:]
-            out += ['`canonical_mlp_kernel` launches in order (ms): ' + ', '.join(f'{x * 1e3:.2f}' for x in d)
+            out += ['`canonical_mlp_lds_kernel` launches in order (ms): ' + ', '.join(f'{x * 1e3:.2f}' for x in d)
                     + f" -- the first {line['warmup']} are warm-up steps; timed-region average "
                     f'{sum(timed) / len(timed) * 1e3:.2f} ms.', '']
             avg = sum(timed) / len(timed)
         tf = FLOP_PER_SAMPLE_CNL * n / avg
         rl = line['roofline']
-        out += [f"`canonical_mlp_kernel`: {avg * 1e3:.2f} ms timed-region average for {n} samples x {FLOP_PER_SAMPLE_CNL} FLOP = "
+        out += [f"`canonical_mlp_lds_kernel`: {avg * 1e3:.2f} ms timed-region average for {n} samples x {FLOP_PER_SAMPLE_CNL} FLOP = "
                 f"{FLOP_PER_SAMPLE_CNL * n / 1e12:.2f} TFLOP -> {tf / 1e12:.1f} TFLOP/s = {100 * tf / PEAK:.1f} % of the "
                 f"157.3 TFLOP/s fp32-MFMA peak. bench.py's HIP-event measurement of the same launches in the "
                 f"un-profiled run: {rl['launch_ms']:.2f} ms ({100 * abs(rl['launch_ms'] - avg * 1e3) / (avg * 1e3):.2f} % "
