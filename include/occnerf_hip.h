@@ -98,6 +98,12 @@ int occnerf_nonrigid_pack(const float *const *h_W, const float *const *h_b, floa
 int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
                      const float *W0, const float *b0, float *packed, float *xyz_out,
                      void *stream);
+/* The first fp32 version (32-sample waves, weights straight from L2); same arguments and packed buffer,
+ * same results to fp32 rounding.  Cross-check and A/B timing; occnerf_nonrigid is the LDS-staged
+ * 16-sample-tile kernel. */
+int occnerf_nonrigid_direct(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
+                            const float *W0, const float *b0, float *packed, float *xyz_out,
+                            void *stream);
 
 /* bf16x3 variant of the non-rigid MLP (split-bf16 operands, fp32 accumulation; see
  * occnerf_canonical_mlp_bf16x3).  packed = the fp32 blob (biases, folded layer-0 bias, output

@@ -26,6 +26,7 @@ SIGNATURES = {
     'occnerf_nonrigid_packed_floats': (_i64, []),
     'occnerf_nonrigid_pack': (C.c_int, [_vp, _vp, _vp, _vp]),
     'occnerf_nonrigid': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_nonrigid_direct': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_nonrigid_packed_bf16_bytes': (_i64, []),
     'occnerf_nonrigid_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_nonrigid_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1,4 +1,6 @@
-// Pose-conditioned non-rigid offset MLP on fp32 MFMA.
+// Pose-conditioned non-rigid offset MLP on fp32 MFMA: the 32-sample-wave
+// direct-load kernel (occnerf_nonrigid_direct; the default is the LDS-staged kernel in nonrigid16.hip) and
+// the split-bf16 variant.
 //
 //   emb = Hann-windowed Fourier embedding of xyz, 6 octaves x (sin, cos) x 3 = 36
 //         (embedders/hannw_fourier.py:9-63; the window is all ones at render time)
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *__
 
 }  // namespace occ
 
-OCC_API int64_t occnerf_nonrigid_packed_floats(void) { return occ::NrBlob::kTotal; }
+OCC_API int64_t occnerf_nonrigid_packed_floats(void) { return occ::NrBlob::kTotal + occ::nr_lds_packed_floats(); }
 
 OCC_API int occnerf_nonrigid_pack(const float *const *h_W, const float *const *h_b, float *packed,
                                   void *stream) {
@@ -469,7 +471,8 @@ OCC_API int occnerf_nonrigid_pack(const float *const *h_W, const float *const *h
                        kNrW, kG_H, packed + NrBlob::kL5W, packed + NrBlob::kL5B);
     hipLaunchKernelGGL(nr_pack_rows_kernel, dim3(2), dim3(256), 0, st, h_W[6], h_b[6],
                        packed + NrBlob::kOutW, packed + NrBlob::kOutB);
-    return check_launch("nonrigid_pack");
+    if (int rc = check_launch("nonrigid_pack")) return rc;
+    return nr_lds_pack(h_W, h_b, packed + NrBlob::kTotal, st);
 }
 
 OCC_API int64_t occnerf_nonrigid_packed_bf16_bytes(void) {
@@ -519,14 +522,22 @@ OCC_API int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, 
     using namespace occ;
     if (N <= 0) return 0;
     OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && xyz_out, "nonrigid: null argument");
+    return nr_lds_launch(xyz_in, N, cond, h_hann, W0, b0, packed + NrBlob::kTotal, xyz_out, as_stream(stream));
+}
+
+OCC_API int occnerf_nonrigid_direct(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
+                                    const float *W0, const float *b0, float *packed, float *xyz_out,
+                                    void *stream) {
+    using namespace occ;
     if (N <= 0) return 0;
+    OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && xyz_out, "nonrigid_direct: null argument");
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(nr_fold_bias_kernel, dim3(1), dim3(128), 0, st, W0, b0, cond, packed + NrBlob::kL0B);
     NrParams prm;
     for (int i = 0; i < 6; i++) prm.hann[i] = h_hann[i];
     const int64_t blocks = (N + 127) / 128;
-    OCC_REQUIRE(blocks < (1ll << 31), "nonrigid: N too large");
+    OCC_REQUIRE(blocks < (1ll << 31), "nonrigid_direct: N too large");
     hipLaunchKernelGGL(nonrigid_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N, packed, prm,
                        xyz_out);
-    return check_launch("nonrigid");
+    return check_launch("nonrigid_direct");
 }

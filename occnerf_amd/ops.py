@@ -150,11 +150,13 @@ def nonrigid_pack(weights, biases):
     return packed
 
 
-def nonrigid(xyz, cond, hann, W0, b0, packed, out=None):
+def nonrigid(xyz, cond, hann, W0, b0, packed, out=None, direct=False):
+    """direct=True: the 32-sample-wave direct-load kernel (cross-check / A-B timing)."""
     out = torch.empty_like(xyz) if out is None else out
     _kh, ph = _host_f32(hann, 6)
+    fn = _lib.lib().occnerf_nonrigid_direct if direct else _lib.lib().occnerf_nonrigid
     with _guard(xyz):
-        rc = _lib.lib().occnerf_nonrigid(
+        rc = fn(
             _chk(xyz, torch.float32, 'xyz'), xyz.shape[0], _chk(cond, torch.float32, 'cond'), ph,
             _chk(W0, torch.float32, 'W0'), _chk(b0, torch.float32, 'b0'),
             _chk(packed, torch.float32, 'packed'), _chk(out, torch.float32, 'xyz_out'), _stream(xyz))

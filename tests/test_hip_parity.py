@@ -389,6 +389,15 @@ def test_nonrigid(case, ops):
         got = ops.nonrigid(T(xyz), T(cond), hann, Wd[0], Bd[0], packed).cpu().numpy()
         want = orc.nonrigid(xyz, cond, hann, W, B)
         assert np.abs(got - want).max() <= 1e-6          # sinf/cosf + MFMA k-order vs libm/serial
+        gotd = ops.nonrigid(T(xyz), T(cond), hann, Wd[0], Bd[0], packed, direct=True).cpu().numpy()
+        assert np.abs(gotd - want).max() <= 1e-6         # the 32-sample-wave direct-load kernel
+    for n in (1, 15, 16, 17, 33, 127, 128, 129):         # partial tiles / waves / workgroups, in place
+        buf = torch.full((n + 2, 3), 5.0, device=DEV)
+        buf[:n] = T(xyz[:n])
+        ops.nonrigid(buf[:n], T(cond), np.ones(6, np.float32), Wd[0], Bd[0], packed, out=buf[:n])
+        got = buf.cpu().numpy()
+        assert np.abs(got[:n] - orc.nonrigid(xyz[:n], cond, np.ones(6, np.float32), W, B)).max() <= 1e-6
+        assert (got[n:] == 5.0).all()
     # split-bf16 variant: offsets are <= ~0.1 m (amplified checkpoint); 2^-17 relative split error per
     # product through 7 layers -> a few 1e-6 m at most
     ph = ops.nonrigid_pack_bf16(Wd)

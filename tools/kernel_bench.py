@@ -42,6 +42,8 @@ def bench_nonrigid():
     r32 = out.clone()
     tb = timeit(lambda: ops.nonrigid_bf16x3(xyz, cond, hann, Wd[0], Bd[0], pk, ph, out=out))
     print(f'nonrigid fp32   : {t32:8.2f} ms')
+    td = timeit(lambda: ops.nonrigid(xyz, cond, hann, Wd[0], Bd[0], pk, out=out, direct=True))
+    print(f'nonrigid direct : {td:8.2f} ms   max|diff| = {float((out - r32).abs().max()):.3e}')
     print(f'nonrigid bf16x3 : {tb:8.2f} ms   max|diff| = {float((out - r32).abs().max()):.3e}')
 
 
