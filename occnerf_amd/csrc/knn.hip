@@ -156,36 +156,44 @@ __global__ __launch_bounds__(256) void msknn_kernel(const float *__restrict__ xy
 // current search radius:  |q - c| - r_cluster > radius(q).  Measured on the benchmark frame
 // this leaves ~1 670 of the 9 152 distance evaluations per sample.  Exactness is unchanged:
 // the test is conservative (fp32 slack included), and because points are no longer visited in
-// row order the k-best lists order equal distances by original row explicitly.
+// row order the k-best lists order equal distances by original row explicitly.  (The brute-force
+// kernel above keeps its own strict-'<' arrival-order insertion: an independent check of the keyed lists.)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool lex_less(float s, int row, float s2, int row2) {
-    return s < s2 || (s == s2 && row < row2);
+// k-best list as ONE fp64 key per entry: high word = the bits of the (non-negative, correctly rounded)
+// fp32 distance, low word = the row.  For such pairs the order of the 64-bit patterns as IEEE doubles is
+// exactly the lexicographic (distance, row) order -- the pattern is never a NaN (a finite or infinite fp32
+// puts at most 0x7F8 into the 11 exponent bits), and fp64 denormals (distance < 2^-119 or 0) are preserved
+// by the kernel's float mode.  Insertion into the sorted list is then a branch-free chain of v_min_f64 /
+// v_max_f64 compare-exchanges: 20 instructions, no compares, no selects, rows carried for free.
+struct KBest64 {
+    double k[kK];
+};
+
+__device__ __forceinline__ double key64(float s, int row) { return __hiloint2double(__float_as_int(s), row); }
+__device__ __forceinline__ float key_dist(double k) { return __int_as_float(__double2hiint(k)); }
+__device__ __forceinline__ int key_row(double k) { return __double2loint(k); }
+
+__device__ __forceinline__ void kbest64_reset(KBest64 &b) {
+#pragma unroll
+    for (int p = 0; p < kK; p++) b.k[p] = key64(INFINITY, 0x7fffffff);
 }
 
-__device__ __forceinline__ void kbest_insert_lex(KBest &b, float s, int row) {
-    b.s[kK - 1] = s;
-    b.i[kK - 1] = row;
+__device__ __forceinline__ void kbest64_insert(KBest64 &b, double t) {
 #pragma unroll
-    for (int p = kK - 1; p > 0; p--) {
-        const bool sw = lex_less(b.s[p], b.i[p], b.s[p - 1], b.i[p - 1]);
-        const float ts = b.s[p - 1];
-        const int ti = b.i[p - 1];
-        b.s[p - 1] = sw ? b.s[p] : ts;
-        b.i[p - 1] = sw ? b.i[p] : ti;
-        b.s[p] = sw ? ts : b.s[p];
-        b.i[p] = sw ? ti : b.i[p];
+    for (int p = 0; p < kK; p++) {
+        double hi;          // the list entry is updated in place: no copies where the divergent branch rejoins
+        asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(b.k[p]), "v"(t));
+        asm("v_min_f64 %0, %0, %1" : "+v"(b.k[p]) : "v"(t));
+        t = hi;
     }
 }
 
 // sb: search radius in distance units (seed or current 10th best), thr: its squared filter
-__device__ __forceinline__ void consider_lex(KBest &b, float &thr, float &sb, float d2, int row) {
+__device__ __forceinline__ void consider_lex(KBest64 &b, float &thr, float &sb, float d2, int row) {
     if (d2 < thr) {
-        const float s = sqrtf(d2);
-        if (lex_less(s, row, b.s[kK - 1], b.i[kK - 1])) {
-            kbest_insert_lex(b, s, row);
-            sb = fminf(sb, b.s[kK - 1]);
-            thr = filter_bound(sb);
-        }
+        kbest64_insert(b, key64(sqrtf(d2), row));
+        sb = fminf(sb, key_dist(b.k[kK - 1]));
+        thr = filter_bound(sb);
     }
 }
 
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
             qy[a >> 1][a & 1] = xyz[qi[a] * 3 + 1];
             qz[a >> 1][a & 1] = xyz[qi[a] * 3 + 2];
         }
-        KBest best[kQ];
+        KBest64 best[kQ];
         float thr[kQ], sb[kQ];
 
 #define OCC_PTL(P, H)                                                                       \
@@ -235,18 +243,26 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
         consider_lex(best[2 * H], thr[2 * H], sb[2 * H], d2[0], row);                       \
         consider_lex(best[2 * H + 1], thr[2 * H + 1], sb[2 * H + 1], d2[1], row);           \
     }
+    /* the next four points are fetched (scalar loads) while the current four are tested */    \
 #define OCC_SCAN(JB, JE)                                                                    \
-    for (int j = (JB); j < (JE); j += 4) {                                                  \
-        const float4 p0 = points[j], p1 = points[j + 1], p2 = points[j + 2], p3 = points[j + 3]; \
-        OCC_PTL(p0, 0) OCC_PTL(p0, 1) OCC_PTL(p1, 0) OCC_PTL(p1, 1)                         \
-        OCC_PTL(p2, 0) OCC_PTL(p2, 1) OCC_PTL(p3, 0) OCC_PTL(p3, 1)                         \
+    {                                                                                       \
+        const int je_ = (JE);                                                               \
+        int j = (JB);                                                                       \
+        float4 n0 = points[j], n1 = points[j + 1], n2 = points[j + 2], n3 = points[j + 3];  \
+        for (; j < je_; j += 4) {                                                           \
+            const float4 p0 = n0, p1 = n1, p2 = n2, p3 = n3;                                \
+            const int jn = j + 4 < je_ ? j + 4 : j;                                         \
+            n0 = points[jn], n1 = points[jn + 1], n2 = points[jn + 2], n3 = points[jn + 3]; \
+            OCC_PTL(p0, 0) OCC_PTL(p0, 1) OCC_PTL(p1, 0) OCC_PTL(p1, 1)                     \
+            OCC_PTL(p2, 0) OCC_PTL(p2, 1) OCC_PTL(p3, 0) OCC_PTL(p3, 1)                     \
+        }                                                                                   \
     }
 #define OCC_EMIT(L)                                                                         \
     _Pragma("unroll") for (int a = 0; a < kQ; a++) {                                        \
         if (live[a]) {                                                                      \
             int32_t *out = knn_idxs + (qi[a] * sc.nscale + (L)) * kK;                       \
             _Pragma("unroll") for (int p = 0; p < kK; p++)                                  \
-                out[p] = index_map[sc.orig_begin[(L)] + best[a].i[p]];                      \
+                out[p] = index_map[sc.orig_begin[(L)] + key_row(best[a].k[p])];                      \
         }                                                                                   \
     }
 
@@ -255,7 +271,7 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
         for (int a = 0; a < kQ; a++) {
             thr[a] = INFINITY;
             sb[a] = INFINITY;
-            kbest_reset(best[a]);
+            kbest64_reset(best[a]);
         }
         OCC_SCAN(sc.coarse_begin, sc.coarse_end)
         OCC_EMIT(sc.nscale - 1)
@@ -263,9 +279,9 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
         for (int l = sc.nscale - 2; l >= 0; l--) {
 #pragma unroll
             for (int a = 0; a < kQ; a++) {
-                sb[a] = sc.seed[l] ? best[a].s[kK - 1] : INFINITY;
+                sb[a] = sc.seed[l] ? key_dist(best[a].k[kK - 1]) : INFINITY;
                 thr[a] = filter_bound(sb[a]);
-                kbest_reset(best[a]);
+                kbest64_reset(best[a]);
             }
             const int2 *rg = ranges + (size_t)l * sc.ncl;
             const float *rd = radius + (size_t)l * sc.ncl;
