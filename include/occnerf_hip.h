@@ -166,10 +166,12 @@ int occnerf_point_sdf(const float *point_cloud, const float *point_base, const d
                       double *knn_base, float *dist, void *stream);
 
 /* Per-point feature table, occnerf_mlp.py:171-175:
- * table[P,36] = [encode((knn_base+bound)/(2 bound), clamp((sdf+0.2)/0.8,0,1)) (32),
- *                learnable xyz (3), 0]  (row padded to 36 floats = 144 B).
+ * table[P,T], T = occnerf_point_table_stride() floats (64: 256-byte rows, so that the 128-byte encoding
+ * part of a gathered row is exactly one cache line); columns
+ *   [encode((knn_base+bound)/(2 bound), clamp((sdf+0.2)/0.8,0,1)) (32), learnable xyz (3), 0, unused...].
  * h_offsets: optional HOST copy of offsets[L+1]; with it the kernel knows per level whether the
  * table is dense or a power-of-two hash and skips the generic 32-bit modulo (same indices). */
+int32_t occnerf_point_table_stride(void);
 int occnerf_point_table(const double *knn_base, const float *point_sdf, const float *learnable,
                         int32_t P, float bound, float two_bound, const float *embeddings,
                         const int32_t *offsets, const int32_t *h_offsets, uint32_t L, float S,

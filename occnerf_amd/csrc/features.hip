@@ -20,7 +20,9 @@
 namespace occ {
 
 constexpr int kKnn = 10;
-constexpr int kTableStride = 36;   // 35 features padded to 36 floats (16-byte rows)
+constexpr int kTableCols = 36;     // 35 features padded to 36 floats
+constexpr int kTableStride = 64;   // row pitch in floats (256 B): the 128-byte encoding part of a row is one cache line,
+                                   // the 3 learnable-xyz floats start the next -- 2 line lookups per gathered row, not 3
 
 // F.cosine_similarity(float32 dir, float64 normal): dir normalised in fp32, normal in fp64,
 // products in fp64 (oracle: oc_cos3).  `un` is the pre-normalised fp64 normal b / max(|b|,eps).
@@ -242,16 +244,16 @@ __global__ __launch_bounds__(256) void sample_features_kernel(
                 ssum = __fadd_rn(ssum, att[j]);
             }
         }
-        float agg[kTableStride];
+        float agg[kTableCols];
 #pragma unroll
-        for (int f = 0; f < kTableStride; f++) agg[f] = 0.0f;
+        for (int f = 0; f < kTableCols; f++) agg[f] = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4 * kKnn; j++) {   // fully unrolled: att[] must stay in registers
             if (j < nk) {
                 const float a = __fdiv_rn(att[j], ssum);
                 const float4 *row = table + (size_t)id[j] * (kTableStride / 4);
 #pragma unroll
-                for (int v = 0; v < kTableStride / 4; v++) {
+                for (int v = 0; v < kTableCols / 4; v++) {
                     const float4 t = row[v];
                     agg[v * 4 + 0] = __fadd_rn(agg[v * 4 + 0], __fmul_rn(a, t.x));
                     agg[v * 4 + 1] = __fadd_rn(agg[v * 4 + 1], __fmul_rn(a, t.y));
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void sample_features_kernel(
         }
         agg[35] = var;    // mlp input layout: [agg 0..34, var, enc 0..31]
 #pragma unroll
-        for (int v = 0; v < kTableStride / 4; v++)
+        for (int v = 0; v < kTableCols / 4; v++)
             *reinterpret_cast<float4 *>(out + v * 4) =
                 make_float4(agg[v * 4], agg[v * 4 + 1], agg[v * 4 + 2], agg[v * 4 + 3]);
     }
@@ -496,6 +498,8 @@ OCC_API int occnerf_point_sdf(const float *point_cloud, const float *point_base,
                        point_base, normals, unit_normals, kidx, P, knn_base, dist);
     return check_launch("point_sdf");
 }
+
+OCC_API int32_t occnerf_point_table_stride(void) { return occ::kTableStride; }
 
 OCC_API int occnerf_point_table(const double *knn_base, const float *point_sdf,
                                 const float *learnable, int32_t P, float bound, float two_bound,

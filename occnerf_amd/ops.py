@@ -250,9 +250,14 @@ def point_sdf(point_cloud, point_base, normals, unit, kidx):
     return kb, dist
 
 
+def table_stride():
+    """Row pitch (floats) of the per-point feature table."""
+    return int(_lib.lib().occnerf_point_table_stride())
+
+
 def point_table(knn_base, sdf, learnable, bound32, two_bound32, embeddings, offsets, S, H):
     P = knn_base.shape[0]
-    table = torch.empty(P, 36, device=knn_base.device, dtype=torch.float32)
+    table = torch.empty(P, table_stride(), device=knn_base.device, dtype=torch.float32)
     with _guard(knn_base):
         rc = _lib.lib().occnerf_point_table(
             _chk(knn_base, torch.float64, 'knn_base'), _chk(sdf, torch.float32, 'point_sdf'),
@@ -269,6 +274,8 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
                     att_in=None):
     N = xyz.shape[0]
     dev = xyz.device
+    if table.dim() != 2 or table.shape[1] != table_stride():
+        raise RuntimeError(f'sample_features: table must be [P,{table_stride()}] (ops.point_table), got {tuple(table.shape)}')
     mlp_in = torch.empty(N, 68, device=dev, dtype=torch.float32)
     raw = torch.empty(N, 5, device=dev, dtype=torch.float32) if raw is None else raw
     enc_in = torch.empty(N, 4, device=dev, dtype=torch.float32) if want_enc_in else None

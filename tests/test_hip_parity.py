@@ -288,7 +288,7 @@ def test_sample_features_and_mlp(case, ops):
     g, ctx, o = case
     m = _dev_model(ctx, ops)
     mlp_in, raw, enc_in = ops.sample_features(T(o['xyz']), T(o['knn']), m['base'], m['normals'], m['unit'],
-                                              T(ctx['counter']), T(np.concatenate([o['table'], np.zeros((o['table'].shape[0], 1), np.float32)], 1)),
+                                              T(ctx['counter']), T(np.concatenate([o['table'], np.zeros((o['table'].shape[0], ops.table_stride() - 35), np.float32)], 1)),
                                               m['b32'], m['tb32'], m['emb'], m['off'], ctx['S'], ctx['H'], want_enc_in=True)
     mi = mlp_in.cpu().numpy()
     same(raw.cpu().numpy()[:, 4], o['raw'][:, 4], 'signed distance')         # bit-exact
