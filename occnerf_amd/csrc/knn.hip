@@ -355,36 +355,48 @@ template <int K>
 __global__ __launch_bounds__(256) void knn_small_kernel(const float *__restrict__ q, int nq,
                                                         const float *__restrict__ s, int ns,
                                                         int32_t *__restrict__ idx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
+    // 8 lanes per query: lane g scans support rows g, g+8, ... into its own sorted list of fp64
+    // (distance,row) keys (see KBest64), then the 8 lists are merged by butterfly exchange.  The key
+    // order is the (distance, row) order, i.e. exactly "strict '<' in row order" of the serial scan.
+    const int g = threadIdx.x & 7;
+    const int i_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int i = i_raw < nq ? i_raw : nq - 1;            // keep all lanes for the shuffles
     const float qx = q[i * 3], qy = q[i * 3 + 1], qz = q[i * 3 + 2];
-    float bs[K];
-    int bi[K];
+    double best[K];
 #pragma unroll
-    for (int p = 0; p < K; p++) {
-        bs[p] = INFINITY;
-        bi[p] = 0;
-    }
-    for (int j = 0; j < ns; j++) {
+    for (int p = 0; p < K; p++) best[p] = key64(INFINITY, 0x7fffffff);
+    for (int j = g; j < ns; j += 8) {
         const float dx = qx - s[j * 3], dy = qy - s[j * 3 + 1], dz = qz - s[j * 3 + 2];
-        const float d = sqrtf(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx))));
-        if (d < bs[K - 1]) {
-            bs[K - 1] = d;
-            bi[K - 1] = j;
+        double t = key64(sqrtf(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)))), j);
+        if (t < best[K - 1]) {
 #pragma unroll
-            for (int p = K - 1; p > 0; p--) {
-                const bool sw = bs[p] < bs[p - 1];
-                const float ts = bs[p - 1];
-                const int ti = bi[p - 1];
-                bs[p - 1] = sw ? bs[p] : ts;
-                bi[p - 1] = sw ? bi[p] : ti;
-                bs[p] = sw ? ts : bs[p];
-                bi[p] = sw ? ti : bi[p];
+            for (int p = 0; p < K; p++) {
+                const double lo = fmin(best[p], t);
+                t = fmax(best[p], t);
+                best[p] = lo;
             }
         }
     }
 #pragma unroll
-    for (int p = 0; p < K; p++) idx[i * K + p] = bi[p];
+    for (int o = 1; o < 8; o <<= 1) {
+        double other[K];
+#pragma unroll
+        for (int p = 0; p < K; p++) other[p] = __shfl_xor(best[p], o, 8);
+#pragma unroll
+        for (int e = 0; e < K; e++) {
+            double t = other[e];
+#pragma unroll
+            for (int p = 0; p < K; p++) {
+                const double lo = fmin(best[p], t);
+                t = fmax(best[p], t);
+                best[p] = lo;
+            }
+        }
+    }
+    if (g == 0 && i_raw < nq) {
+#pragma unroll
+        for (int p = 0; p < K; p++) idx[i * K + p] = key_row(best[p]);
+    }
 }
 
 }  // namespace occ
@@ -457,8 +469,8 @@ OCC_API int occnerf_knn_small(const float *q, int32_t nq, const float *s, int32_
     OCC_REQUIRE(q && s && idx, "knn_small: null argument");
     OCC_REQUIRE(ns >= k, "knn_small: fewer support points (%d) than k (%d)", ns, k);
     if (nq <= 0) return 0;
-    // a few thousand queries at most: 64-thread blocks spread them over more CUs
-    const dim3 grid((nq + 63) / 64), block(64);
+    // a few thousand queries at most: 8 lanes per query, 64-thread blocks spread them over the CUs
+    const dim3 grid((nq + 7) / 8), block(64);
     hipStream_t st = as_stream(stream);
     switch (k) {
         case 1: hipLaunchKernelGGL((knn_small_kernel<1>), grid, block, 0, st, q, nq, s, ns, idx); break;
