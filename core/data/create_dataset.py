@@ -38,7 +38,8 @@ class SyntheticFrames:
             frame = synth.make_frame(
                 img_size=self.img_size, pose72=self._pose(idx),
                 orbit_frame=idx if self.data_type == 'freeview' else 0,
-                orbit_period=max(self.total_frames, 1), bgcolor=cfg.bgcolor)
+                orbit_period=max(self.total_frames, 1), bgcolor=cfg.bgcolor,
+                with_rays=not bool(cfg.get('device_rays', True)))
             batch = {}
             for k, v in frame.items():
                 batch[k] = torch.as_tensor(np.asarray(v))[None] if not np.isscalar(v) else v

@@ -84,6 +84,19 @@ int occnerf_sample_warp(const float *rays, int64_t n, int32_t S, const float *t_
                         int32_t nb, int32_t G, const float *h_bbox_min, const float *h_bbox_scale,
                         float *z_vals, float *pts, float *x_skel, float *mask, void *stream);
 
+/* Per-frame ray generation (one thread per pixel): camera_util.py:133-160 get_rays_from_KRT +
+ * :163-212 rays_intersect_3d_bbox, as the reference's datasets call them (tpose.py:155-172,
+ * freeview.py:190-208).  HOST inputs: h_Kinv[9] = K^-1, h_R[9], h_T[3] (E[:3,:3], E[:3,3]), row major,
+ * h_bbox_min/max[3] = the observation-space skeleton bbox (the 0.01 growth is applied inside);
+ * f32_camera != 0: K and E were float32 arrays, so numpy ran pixel -> ray in float32 (the reference's
+ * synthetic tpose / freeview cameras); 0: float64 (calibrated dataset cameras).
+ * Outputs for every pixel p = row * W + col: rays8[p] = (origin, direction with |d|<1e-5 clamped as the
+ * reference clamps it, near, far) and mask[p] = 1 when the ray crosses the box (exactly two face hits);
+ * near/far are 0 where mask is 0.  The caller compacts by mask (occnerf_amd/rays.py). */
+int occnerf_gen_rays(const double *h_Kinv, const double *h_R, const double *h_T, int32_t f32_camera,
+                     int32_t H, int32_t W, const double *h_bbox_min, const double *h_bbox_max, float *rays8,
+                     uint8_t *mask, void *stream);
+
 /* Non-rigid offset MLP (105 -> 128 x6 (skip @4) -> 3) with the Hann-windowed Fourier
  * embedding.  Replaces embedders/hannw_fourier.py:9-63 + mlp_offset.py:45-62 as called at
  * network.py:225-232.

@@ -117,6 +117,34 @@ def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, Cc, L,
     _lib.check(rc, 'grad_total_variation')
 
 
+# ------------------------------------------------------------------ per-frame ray generation
+def _host_f64(vals, n):
+    a = np.ascontiguousarray(np.asarray(vals, dtype=np.float64).ravel())
+    assert a.size == n, (a.size, n)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def gen_rays(K, E, H, W, bbox_min, bbox_max, device):
+    """All H*W pixel rays of a camera on the device -> rays8[H*W,8] (o, d, near, far), mask[H*W] uint8."""
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise RuntimeError(f'gen_rays: needs a GPU device, got {dev}')
+    f32 = int(np.asarray(K).dtype == np.float32 and np.asarray(E).dtype == np.float32)   # numpy's result dtype
+    E = np.asarray(E, dtype=np.float64)
+    k0, pk = _host_f64(np.linalg.inv(np.asarray(K)).astype(np.float64), 9)      # inverse in K's own dtype
+    r0, pr = _host_f64(E[:3, :3], 9)
+    t0, pt = _host_f64(E[:3, 3], 3)
+    l0, pl = _host_f64(bbox_min, 3)
+    h0, ph = _host_f64(bbox_max, 3)
+    rays8 = torch.empty(H * W, 8, device=dev, dtype=torch.float32)
+    mask = torch.empty(H * W, device=dev, dtype=torch.uint8)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_gen_rays(pk, pr, pt, f32, int(H), int(W), pl, ph, rays8.data_ptr(),
+                                         mask.data_ptr(), _stream(rays8))
+    _lib.check(rc, 'gen_rays')
+    return rays8, mask
+
+
 # ------------------------------------------------------------------ sample pipeline (section 2)
 def sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale, t_rand=None, want_pts=False):
     """rays8[n,8] -> z_vals[n,S], x_skel[n*S,3], mask[n*S] (, pts[n*S,3])."""

@@ -387,9 +387,8 @@ def rays_intersect_3d_bbox(bounds, ray_o, ray_d):
     bounds = np.stack([bounds['min_xyz'], bounds['max_xyz']], 0) if isinstance(bounds, dict) \
         else np.asarray(bounds)
     bounds = bounds + np.array([-0.01, 0.01])[:, None]
-    ray_d = ray_d.copy()
     nominator = bounds[None] - ray_o[:, None]
-    ray_d[np.abs(ray_d) < 1e-5] = 1e-5
+    ray_d[np.abs(ray_d) < 1e-5] = 1e-5          # in place, as the reference: the caller's directions are clamped too
     d_int = (nominator / ray_d[:, None]).reshape(-1, 6)
     p_int = d_int[..., None] * ray_d[:, None] + ray_o[:, None]
     lo, hi = bounds[0] - 1e-6, bounds[1] + 1e-6
@@ -432,9 +431,10 @@ def posed_joints(pose72, tjoints):
 
 def make_frame(img_size=512, pose72=None, orbit_frame=0, orbit_period=100,
                bgcolor=(255.0, 255.0, 255.0), betas=None, bbox_offset=0.3, volume_size=32,
-               rotate_axis='y'):
+               rotate_axis='y', with_rays=True):
     """One frame of renderer inputs, T-pose (pose72 None/zeros, tpose.py:133-217) or a
-    posed free-view orbit frame (freeview.py:177-269)."""
+    posed free-view orbit frame (freeview.py:177-269).  with_rays=False leaves the ray batch to the device
+    (occnerf_amd/rays.py) and returns the camera and the observation-space bbox instead."""
     betas = np.zeros(10, dtype='float32') if betas is None else betas
     cjoints = tpose_joints(betas).astype('float32')
     cbbox = skeleton_to_bbox(cjoints, bbox_offset)
@@ -447,19 +447,23 @@ def make_frame(img_size=512, pose72=None, orbit_frame=0, orbit_period=100,
         angle = 2 * np.pi * (orbit_frame / orbit_period)
         E = rotate_camera(E, angle, rotate_axis=rotate_axis).astype('float32')
     R, T = E[:3, :3], E[:3, 3]
-    rays_o, rays_d = get_rays_from_KRT(img_size, img_size, K, R, T)
-    rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
-    near, far, ray_mask = rays_intersect_3d_bbox(dst_bbox, rays_o, rays_d)
-    rays_o, rays_d = rays_o[ray_mask], rays_d[ray_mask]
+    if with_rays:
+        rays_o, rays_d = get_rays_from_KRT(img_size, img_size, K, R, T)
+        rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        near, far, ray_mask = rays_intersect_3d_bbox(dst_bbox, rays_o, rays_d)
+        rays_o, rays_d = rays_o[ray_mask], rays_d[ray_mask]
+        ray_part = {'ray_mask': ray_mask, 'rays': np.stack([rays_o, rays_d], 0).astype('float32'),
+                    'near': near[:, None].astype('float32'), 'far': far[:, None].astype('float32')}
+    else:
+        ray_part = {'camera_K': K, 'camera_E': E, 'dst_bbox_min': dst_bbox['min_xyz'],
+                    'dst_bbox_max': dst_bbox['max_xyz']}
 
     dst_Rs, dst_Ts = body_pose_to_body_RTs(pose, cjoints)
     prior = approx_gaussian_bone_volumes(cjoints, cbbox['min_xyz'], cbbox['max_xyz'],
                                          grid_size=volume_size).astype('float32')
     mn, mx = cbbox['min_xyz'].astype('float32'), cbbox['max_xyz'].astype('float32')
     return {
-        'img_width': img_size, 'img_height': img_size, 'ray_mask': ray_mask,
-        'rays': np.stack([rays_o, rays_d], 0).astype('float32'),
-        'near': near[:, None].astype('float32'), 'far': far[:, None].astype('float32'),
+        'img_width': img_size, 'img_height': img_size, **ray_part,
         'bgcolor': np.array(bgcolor, dtype='float32'),
         'dst_Rs': dst_Rs, 'dst_Ts': dst_Ts,
         'cnl_gtfms': get_canonical_global_tfms(cjoints),

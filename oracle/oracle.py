@@ -224,3 +224,35 @@ def raw2outputs(raw, mask, z_vals, rays_d, bgcolor):
                          _p(bg, _f32p), C.c_int64(n), C.c_int(S), _p(rgb, _f32p), _p(acc, _f32p),
                          _p(dep, _f32p), _p(w, _f32p), _p(tp, _i32p))
     return rgb, acc, w, dep, tp
+
+
+# ----------------------------------------------------------------------------- ray generation
+def gen_rays(K, E, H, W, bbox_min, bbox_max):
+    """camera_util.py:133-160 (get_rays_from_KRT) + :163-212 (rays_intersect_3d_bbox), as chained at
+    tpose.py:155-172: all pixels -> rays_o[H*W,3], rays_d[H*W,3] (clamped in place like the reference),
+    near[R], far[R], mask[H*W].  Dtypes are left to numpy exactly as in the reference: a float32 camera
+    (tpose.py:66-84) gives float32 rays, a float64 one float64 rays; the box stage is float64 either way."""
+    K, E = np.asarray(K), np.asarray(E)
+    R, T = E[:3, :3], E[:3, 3]
+    rays_o = -np.dot(R.T, T).ravel()                                            # :149
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
+    xy1 = np.stack([i, j, np.ones_like(i)], axis=2)                             # :151-154
+    pixel_camera = np.dot(xy1, np.linalg.inv(K).T)                              # :155
+    pixel_world = np.dot(pixel_camera - T.ravel(), R)                           # :156
+    ray_d = (pixel_world - rays_o[None, None]).reshape(-1, 3).copy()              # :158
+    ray_o = np.broadcast_to(rays_o, ray_d.shape)
+    bounds = np.stack([np.asarray(bbox_min, np.float64), np.asarray(bbox_max, np.float64)], 0)
+    bounds = bounds + np.array([-0.01, 0.01])[:, None]                          # :181
+    nominator = bounds[None] - ray_o[:, None]
+    ray_d[np.abs(ray_d) < 1e-5] = 1e-5                                          # :184 (in place in the reference)
+    d_intersect = (nominator / ray_d[:, None]).reshape(-1, 6)
+    p_intersect = d_intersect[..., None] * ray_d[:, None] + ray_o[:, None]
+    lo, hi = bounds[0] - 1e-6, bounds[1] + 1e-6                                 # :190-197
+    at_box = np.all((p_intersect >= lo) & (p_intersect <= hi), axis=-1)
+    mask = at_box.sum(-1) == 2                                                  # :199
+    p_iv = p_intersect[mask][at_box[mask]].reshape(-1, 2, 3)
+    ro, rd = ray_o[mask], ray_d[mask]
+    nrm = np.linalg.norm(rd, axis=1)
+    d0 = np.linalg.norm(p_iv[:, 0] - ro, axis=1) / nrm
+    d1 = np.linalg.norm(p_iv[:, 1] - ro, axis=1) / nrm
+    return ray_o, ray_d, np.minimum(d0, d1), np.maximum(d0, d1), mask

@@ -340,9 +340,39 @@ def run_image_case(name, img_size, S, seed=0):
     print('   rays', frame['rays'].shape[1], '-> wrote', path, f'{os.path.getsize(path) / 1e6:.2f} MB')
 
 
+def run_rays_case(name):
+    """Ray generation: the reference's own camera_util functions on three cameras -- the float32 T-pose
+    camera (tpose.py:66-84), a float32 orbit camera (freeview), and a float64 'calibrated' camera."""
+    cj = synth.tpose_joints(np.zeros(10)).astype('float32')
+    out = {}
+    for tag, img, pose, orbit, f64 in (('t32', 48, None, 0, False), ('f32', 40, synth.seeded_pose(1), 7, False),
+                                       ('c64', 36, synth.seeded_pose(2), 3, True)):
+        K, E = synth.setup_camera(img)
+        if orbit:
+            E = ref_cam.rotate_camera_by_frame_idx(extrinsics=E, frame_idx=orbit, period=20).astype('float32')
+        if f64:
+            K, E = K.astype('float64'), E.astype('float64')
+            K[0, 2] += 0.37                                      # off-centre principal point
+        joints = cj if pose is None else synth.posed_joints(pose, cj)
+        bb = synth.skeleton_to_bbox(joints, 0.3)
+        R, T = E[:3, :3], E[:3, 3]
+        ro, rd = ref_cam.get_rays_from_KRT(img, img, K, R, T)
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        near, far, mask = ref_cam.rays_intersect_3d_bbox(bb, ro, rd)     # clamps rd in place
+        out.update({f'{tag}.K': K, f'{tag}.E': E, f'{tag}.img': np.int32(img), f'{tag}.bbox_min': bb['min_xyz'],
+                    f'{tag}.bbox_max': bb['max_xyz'], f'{tag}.rays_o': np.ascontiguousarray(ro),
+                    f'{tag}.rays_d': rd, f'{tag}.near': near, f'{tag}.far': far, f'{tag}.mask': mask})
+        print('   rays case', tag, 'kept', int(mask.sum()), 'of', img * img, 'dtype', rd.dtype)
+    path = os.path.join(OUT_DIR, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('   wrote', path, f'{os.path.getsize(path) / 1e6:.2f} MB')
+
+
 if __name__ == '__main__':
     os.makedirs(OUT_DIR, exist_ok=True)
     which = CASES
+    if 'all' in which or 'rays' in which:
+        run_rays_case('rays_cameras')
     if 'all' in which or 'tpose' in which:
         run_case('tpose_ri_s32', img_size=32, S=32, amplify=False, keep_rays=160)
     if 'all' in which or 'tpose128' in which:

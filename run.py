@@ -17,8 +17,10 @@ cfg.bgcolor = [255., 255., 255.]
 from core.data import create_dataloader  # noqa: E402
 from core.nets import create_network  # noqa: E402
 from occnerf_amd.image import ImageWriter, assemble_uint8_device  # noqa: E402
+from occnerf_amd.rays import frame_rays  # noqa: E402
 
-EXCLUDE_KEYS_TO_GPU = ['frame_name', 'img_width', 'img_height', 'ray_mask']
+EXCLUDE_KEYS_TO_GPU = ['frame_name', 'img_width', 'img_height', 'ray_mask',
+                       'camera_K', 'camera_E', 'dst_bbox_min', 'dst_bbox_max']
 
 
 def load_network(model):
@@ -50,9 +52,16 @@ def _render(data_type, folder_name):
     for idx, batch in enumerate(loader):
         batch = {k: (v[0] if torch.is_tensor(v) or isinstance(v, list) else v) for k, v in batch.items()}
         data = {k: v.cuda() for k, v in batch.items() if k not in EXCLUDE_KEYS_TO_GPU and torch.is_tensor(v)}
-        ray_index = torch.nonzero(batch['ray_mask'].cuda()).squeeze(1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if 'rays' not in batch:          # cfg.device_rays: the ray batch is generated on the GPU (occnerf_amd/rays.py)
+            fr = frame_rays(batch['camera_K'].numpy(), batch['camera_E'].numpy(), int(batch['img_height']),
+                            int(batch['img_width']), batch['dst_bbox_min'].numpy(), batch['dst_bbox_max'].numpy(),
+                            'cuda')
+            data.update(rays=fr['rays'], near=fr['near'], far=fr['far'])
+            ray_index = torch.nonzero(fr['ray_mask']).squeeze(1)
+        else:
+            ray_index = torch.nonzero(batch['ray_mask'].cuda()).squeeze(1)
         with torch.no_grad():
             out = model(**data, iter_val=cfg.eval_iter)
         rgb_img, alpha_img = assemble_uint8_device(int(batch['img_width']), int(batch['img_height']), ray_index,

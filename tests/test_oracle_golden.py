@@ -1,5 +1,6 @@
 """CPU: the C oracle against golden vectors recorded from the reference's own Python
 (oracle/ref_harness/make_golden.py).  This is what pins the oracle (prompt rule 3)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -149,3 +150,19 @@ def test_composite(case, oracle):
     assert np.abs(w - g['comp.weights']).max() <= 2e-6
     assert np.array_equal(tp, g['comp.term'].ravel())
     assert np.array_equal(g['comp.rgb'], g['out.rgb'])
+
+
+# ----------------------------------------------------------------------------- ray generation
+@pytest.mark.parametrize('tag', ['t32', 'f32', 'c64'])
+def test_gen_rays_oracle(tag):
+    """oracle.gen_rays against the reference's own camera_util functions (golden rays_cameras.npz:
+    float32 T-pose camera, float32 orbit camera, float64 off-centre camera)."""
+    from oracle import oracle as orc
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'rays_cameras.npz'))
+    img = int(g[f'{tag}.img'])
+    ro, rd, near, far, mask = orc.gen_rays(g[f'{tag}.K'], g[f'{tag}.E'], img, img, g[f'{tag}.bbox_min'],
+                                           g[f'{tag}.bbox_max'])
+    assert np.array_equal(mask, g[f'{tag}.mask'])
+    assert rd.dtype == g[f'{tag}.rays_d'].dtype
+    assert np.array_equal(rd, g[f'{tag}.rays_d']) and np.array_equal(ro, g[f'{tag}.rays_o'])
+    assert np.array_equal(near, g[f'{tag}.near']) and np.array_equal(far, g[f'{tag}.far'])
