@@ -67,16 +67,32 @@ class MotionBasisComputer(nn.Module):
         super().__init__()
         self.total_bones = total_bones
 
+    def _levels(self, nb, device):
+        cache = self.__dict__.setdefault('_level_cache', {})
+        key = (nb, str(device))
+        if key not in cache:
+            depth = [0] * nb
+            for i in range(1, nb):
+                depth[i] = depth[SMPL_PARENT[i]] + 1
+            lv = []
+            for dpt in range(1, max(depth) + 1):
+                js = [i for i in range(nb) if depth[i] == dpt]
+                lv.append((torch.tensor(js, device=device), torch.tensor([SMPL_PARENT[i] for i in js], device=device)))
+            cache[key] = lv
+        return cache[key]
+
     def forward(self, dst_Rs, dst_Ts, cnl_gtfms):
         B, nb = dst_Rs.shape[:2]
         local = torch.zeros(B, nb, 4, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)
         local[:, :, :3, :3] = dst_Rs
         local[:, :, :3, 3] = dst_Ts
         local[:, :, 3, 3] = 1.0
-        chain = [local[:, 0]]
-        for i in range(1, nb):
-            chain.append(torch.matmul(chain[SMPL_PARENT[i]], local[:, i]))
-        dst = torch.stack(chain, dim=1).view(-1, 4, 4)
+        # forward kinematics level by level of the tree (8 batched products instead of 23 single ones;
+        # each joint still gets exactly parent_global @ local)
+        glob = local.clone()
+        for joints, parents in self._levels(nb, dst_Rs.device):
+            glob[:, joints] = torch.matmul(glob[:, parents], local[:, joints])
+        dst = glob.view(-1, 4, 4)
         f = torch.matmul(cnl_gtfms.view(-1, 4, 4), torch.inverse(dst)).view(B, nb, 4, 4)
         return f[:, :, :3, :3], f[:, :, :3, 3]
 
@@ -124,21 +140,35 @@ class _ConvDecoder3D(nn.Module):
             self._wp, self._wp_key = packed, key
         return self._wp
 
+    def _patch_index(self, D, H, Wd, device):
+        """Flat indices into the zero-padded [D+2, H+2, W+2] input of the 8 taps of every output parity
+        class: idx[parity, voxel, tap] (cached per input size; one gather then builds all 8 patch matrices
+        of a layer instead of 64 slice copies + 8 concatenations)."""
+        cache = self.__dict__.setdefault('_patch_idx', {})
+        key = (D, H, Wd, str(device))
+        if key not in cache:
+            d, h, w = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(Wd), indexing='ij')
+            per_parity = []
+            for pd in (0, 1):
+                for ph in (0, 1):
+                    for pw in (0, 1):
+                        taps = [((d + od) * (H + 2) + (h + oh)) * (Wd + 2) + (w + ow)
+                                for _, od in self._TAPS[pd] for _, oh in self._TAPS[ph]
+                                for _, ow in self._TAPS[pw]]
+                        per_parity.append(torch.stack([t.reshape(-1) for t in taps], 1))     # [DHW, 8]
+            cache[key] = torch.stack(per_parity, 0).to(device)                                # [8, DHW, 8]
+        return cache[key]
+
     def forward_gemm(self, embedding):
         x = self.block_mlp(embedding).view(1024, 1, 1, 1)               # [C, D, H, W], batch 1
         convs = [m for m in self.block_conv if isinstance(m, nn.ConvTranspose3d)]
         for li, (m, Wp) in enumerate(zip(convs, self._packed_conv_weights())):
             C, D, H, Wd = x.shape
-            xp = F.pad(x, (1, 1, 1, 1, 1, 1))
-            patches = []
-            for pd in (0, 1):
-                for ph in (0, 1):
-                    for pw in (0, 1):
-                        taps = [xp[:, od:od + D, oh:oh + H, ow:ow + Wd].reshape(C, -1)
-                                for _, od in self._TAPS[pd] for _, oh in self._TAPS[ph]
-                                for _, ow in self._TAPS[pw]]
-                        patches.append(torch.cat(taps, 0).t())          # [DHW, 8 C]
-            y = torch.bmm(torch.stack(patches, 0), Wp)                   # [8, DHW, Cout]
+            idx = self._patch_index(D, H, Wd, x.device)
+            xp = F.pad(x, (1, 1, 1, 1, 1, 1)).reshape(C, -1)
+            # patches[parity, voxel, tap * C + c] = xp[c, idx[parity, voxel, tap]]
+            patches = xp[:, idx.reshape(-1)].view(C, 8, D * H * Wd, 8).permute(1, 2, 3, 0).reshape(8, D * H * Wd, 8 * C)
+            y = torch.bmm(patches, Wp)                                   # [8, DHW, Cout]
             Co = y.shape[-1]
             y = y.view(2, 2, 2, D, H, Wd, Co).permute(6, 3, 0, 4, 1, 5, 2).reshape(Co, 2 * D, 2 * H, 2 * Wd)
             y = y + m.bias.view(-1, 1, 1, 1)
