@@ -129,6 +129,17 @@ struct FeatParams {
     int nscale, L;
 };
 
+// Everything sample_features8_kernel needs to know about a level, in one 16-byte record: a lane picks its
+// two levels with two 16-byte loads instead of ten dword loads from five arrays.
+struct LevelRec4 {
+    uint32_t entry0, size;      // first table entry of the level, entries in it
+    float scale;
+    uint32_t res_mode;          // resolution | mode << 24
+};
+struct LevelRecs {
+    LevelRec4 r[kMaxLevels];
+};
+
 __global__ __launch_bounds__(256) void sample_features_kernel(
     const float *__restrict__ xyz, int64_t N, const int32_t *__restrict__ knn_idxs,
     const float *__restrict__ point_base, const double *__restrict__ normals,
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
     const float *__restrict__ point_base, const double *__restrict__ normals,
     const double *__restrict__ unit, const float *__restrict__ counter,
     const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
-    const int32_t *__restrict__ offsets, GridLevels lv, GridModes4 gm, FeatParams prm,
+    LevelRecs levels, FeatParams prm,
     float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
     constexpr int NK = 4 * kKnn;                       // 40 neighbours over 4 scales
     const int g = threadIdx.x & 7;
@@ -318,7 +329,9 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
         const bool live = i_raw < N;
         const int64_t i = live ? i_raw : N - 1;         // keep every lane in the shuffles
         const int32_t *id = knn_idxs + i * NK;
-        const float p[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+        struct __attribute__((packed, aligned(4))) F3 { float v[3]; };
+        const F3 pq = *reinterpret_cast<const F3 *>(xyz + i * 3);               // one 12-byte load
+        const float p[3] = {pq.v[0], pq.v[1], pq.v[2]};
 
         // ---- neighbour geometry: lane g owns neighbour g, lanes 0/1 also 8/9 ----
         float nrm[2];
@@ -390,22 +403,31 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
         if (!oob) {
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-                const int l = 2 * g + a;
-                const uint32_t o0 = (uint32_t)offsets[l];
-                ev[a] = encode_level_d4c2(x, embeddings, (uint32_t)offsets[l + 1] - o0, lv.scale[l],
-                                          lv.resolution[l], gm.mode[l], o0);
+                const LevelRec4 lr = levels.r[2 * g + a];
+                ev[a] = encode_level_d4c2(x, embeddings, lr.size, lr.scale, lr.res_mode & 0xFFFFFFu, lr.res_mode >> 24,
+                                          lr.entry0);
             }
         }
         if (live) *reinterpret_cast<float4 *>(out + 36 + 4 * g) = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);
 
         // ---- visibility softmax: lane g owns neighbours 5g..5g+4 ----
+        // (the lane also fetches the learnable-xyz tail, columns 32..34, of ITS five rows here: 5 gather
+        // instructions for the 40 tails of a sample instead of 40 one-lane-in-eight ones in the row loop --
+        // the texture addresser's cost is per instruction, not per byte)
         int id5[5];
         float a5[5];
+        float4 tl[5];
         float lmin = INFINITY;
+        {       // rows 5g..5g+4: 20 contiguous bytes, dword aligned -> one 16-byte load + one dword
+            struct __attribute__((packed, aligned(4))) I4 { int v[4]; };
+            const I4 q = *reinterpret_cast<const I4 *>(id + g * 5);
+            id5[0] = q.v[0], id5[1] = q.v[1], id5[2] = q.v[2], id5[3] = q.v[3];
+            id5[4] = id[g * 5 + 4];
+        }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            id5[k] = id[g * 5 + k];
             a5[k] = ld32(counter, (uint32_t)id5[k] * 4u);
+            tl[k] = ld32(table, (uint32_t)id5[k] * (uint32_t)(kTableStride * 4) + 128u);
             lmin = fminf(lmin, a5[k]);
         }
         const float amin = grp_min8(lmin);
@@ -442,13 +464,18 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
 #pragma unroll
         for (int k = 0; k < 5; k++) a5[k] = __fdiv_rn(a5[k], ssum);
 
-        // ---- gather the 40 rows: 128 B of encoding per row across the 8 lanes, tail on lane j&7 ----
+        // ---- gather the 40 rows: 128 B of encoding per row across the 8 lanes ----
         float agg[4] = {0.f, 0.f, 0.f, 0.f}, tail[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            tail[0] += a5[k] * tl[k].x;
+            tail[1] += a5[k] * tl[k].y;
+            tail[2] += a5[k] * tl[k].z;
+        }
 #pragma unroll 1
         for (int o = 0; o < 8; o++) {                   // owner lane of neighbours 5o..5o+4
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                const int j = o * 5 + k;
                 const int rowid = __shfl(id5[k], o, 8);
                 const float w = __shfl(a5[k], o, 8);
                 const uint32_t row = (uint32_t)rowid * (uint32_t)(kTableStride * 4);      // byte offset of the row
@@ -457,12 +484,6 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
                 agg[1] = __fadd_rn(agg[1], __fmul_rn(w, t.y));
                 agg[2] = __fadd_rn(agg[2], __fmul_rn(w, t.z));
                 agg[3] = __fadd_rn(agg[3], __fmul_rn(w, t.w));
-                if (g == (j & 7)) {
-                    const float4 tt = ld32(table, row + 128u);
-                    tail[0] += w * tt.x;
-                    tail[1] += w * tt.y;
-                    tail[2] += w * tt.z;
-                }
             }
         }
 #pragma unroll
@@ -537,13 +558,17 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
     const GridLevels lv = make_grid_levels(L, S, H);
     const GridModes4 gm = modes_from_host_offsets(L, lv, h_offsets);
     FeatParams prm{bound, two_bound, nscale, (int)L};
-    if (nscale == 4 && !geo_idxs && !att_in && counter) {      // the renderer's call: 8 lanes per sample
+    if (nscale == 4 && !geo_idxs && !att_in && counter && h_offsets) {      // the renderer's call: 8 lanes per sample
+        LevelRecs levels;
+        for (uint32_t l = 0; l < kMaxLevels; l++)
+            levels.r[l] = LevelRec4{(uint32_t)h_offsets[l], (uint32_t)(h_offsets[l + 1] - h_offsets[l]), lv.scale[l],
+                                    lv.resolution[l] | (gm.mode[l] << 24)};
         int64_t blocks8 = (N + 31) / 32;
         if (blocks8 > (int64_t)kNumCU * 32) blocks8 = (int64_t)kNumCU * 32;
         hipLaunchKernelGGL(sample_features8_kernel, dim3((unsigned)blocks8), dim3(256), 0, as_stream(stream), xyz,
                            N, knn_idxs, point_base, normals, unit_normals, counter,
                            reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),
-                           offsets, lv, gm, prm, mlp_in, raw, enc_in);
+                           levels, prm, mlp_in, raw, enc_in);
         return check_launch("sample_features");
     }
     int64_t blocks = (N + 255) / 256;
