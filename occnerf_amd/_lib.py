@@ -64,6 +64,10 @@ def lib():
                 f'{LIB_PATH} not found: the gfx950 kernels are not built. Run '
                 '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C '
                 'occnerf_amd/csrc`). There is no CPU fallback for this path.')
+        # torch first: it ships its own libamdhip64 and the kernels must run on the HIP runtime that owns
+        # torch's streams and allocations.  Loading this library first would bring in /opt/rocm's copy and
+        # leave two runtimes in the process ("no ROCm-capable device is detected" on the first launch).
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)            # AttributeError if the ABI drifted
