@@ -208,6 +208,15 @@ int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs
                             const int32_t *geo_idxs, const float *att_in,
                             float *mlp_in, float *raw, float *enc_in, void *stream);
 
+/* Differentiable neighbour aggregation of the training path (occnerf_mlp.py:86-126 simple_agg with the
+ * gather of :176-178): agg[n,:] = sum_j atts[n,j] * feats[knn[n,j],:] for feats[P,F] (F <= 64), knn[N,K],
+ * atts[N,K] (detached in the reference), and its gradient scattered into grad_feats[P,F] (accumulated: zero
+ * it first) with fp32 atomics.  Replaces torch's feats[knn] materialisation and index_put backward. */
+int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *knn, const float *atts, int64_t N, int32_t K,
+                        float *agg, void *stream);
+int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t *knn, const float *atts, int64_t N,
+                         int32_t K, float *grad_feats, void *stream);
+
 /* Canonical MLP weights -> MFMA operand order.  h_W/h_b: HOST arrays of the 10 device
  * weight/bias pointers in module order: pts_linears.{0,2,4,6}, geo_linear.0,
  * rgb_linears.{0,2,4,6}, output_linear.0 (torch layout [out,in]).  packed: device buffer of

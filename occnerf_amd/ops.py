@@ -383,3 +383,47 @@ def composite(raw, mask, z_vals, rays8, bgcolor, want_weights=False, want_term=F
             None if tp is None else tp.data_ptr(), _stream(raw))
     _lib.check(rc, 'composite')
     return rgb, acc, dep, w, tp
+
+
+# ------------------------------------------------------------------ training path: neighbour aggregation
+def agg_forward(feats, knn, atts):
+    """agg[n] = sum_j atts[n,j] * feats[knn[n,j]]  (feats[P,F] fp32, knn[N,K] int32, atts[N,K] fp32)."""
+    N, K = knn.shape
+    F = feats.shape[1]
+    agg = torch.empty(N, F, device=feats.device, dtype=torch.float32)
+    with _guard(feats):
+        rc = _lib.lib().occnerf_agg_forward(_chk(feats, torch.float32, 'feats'), int(F), _chk(knn, torch.int32, 'knn'),
+                                            _chk(atts, torch.float32, 'atts'), N, int(K), agg.data_ptr(), _stream(feats))
+    _lib.check(rc, 'agg_forward')
+    return agg
+
+
+def agg_backward(grad_agg, knn, atts, P):
+    N, K = knn.shape
+    F = grad_agg.shape[1]
+    grad_feats = torch.zeros(P, F, device=grad_agg.device, dtype=torch.float32)
+    with _guard(grad_agg):
+        rc = _lib.lib().occnerf_agg_backward(_chk(grad_agg, torch.float32, 'grad_agg'), int(F),
+                                             _chk(knn, torch.int32, 'knn'), _chk(atts, torch.float32, 'atts'), N,
+                                             int(K), grad_feats.data_ptr(), _stream(grad_agg))
+    _lib.check(rc, 'agg_backward')
+    return grad_feats
+
+
+class _Aggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, knn, atts):
+        feats = feats.contiguous()
+        ctx.save_for_backward(knn, atts)
+        ctx.P = feats.shape[0]
+        return agg_forward(feats, knn, atts)
+
+    @staticmethod
+    def backward(ctx, grad_agg):
+        knn, atts = ctx.saved_tensors
+        return agg_backward(grad_agg.contiguous(), knn, atts, ctx.P), None, None
+
+
+def aggregate(feats, knn, atts):
+    """Differentiable (w.r.t. feats) weighted neighbour sum; knn and atts carry no gradient."""
+    return _Aggregate.apply(feats, knn.contiguous(), atts.contiguous())

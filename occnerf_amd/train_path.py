@@ -92,13 +92,14 @@ def canonical_mlp_torch(cm, xyz, knn_idxs, net, knn_base, point_sdf):
     sdf01 = torch.clamp((point_sdf + 0.2) / 0.8, 0.0, 1.0)
     feats = cm.encoder(torch.cat((pc01, sdf01), dim=-1).float(), bound=None)
     feats = torch.cat((feats, net.point_cloud.float()), dim=-1)                  # [P,35]
-    gathered = feats[knn_idxs.long()].view(N, -1, feats.shape[-1])               # [N,40,35]
     atts = net.point_counter.detach()[knn_idxs.long()].view(N, -1, 1).clone()
     atts = atts + (1. - atts.min(dim=1, keepdim=True)[0])
     atts = atts / atts.max(dim=1, keepdim=True)[0]
     var = torch.var(atts, dim=1)
     atts = F.softmax(atts, dim=1)
-    agg = torch.sum(atts.detach() * gathered, dim=1)
+    # sum_j atts[n,j] * feats[knn[n,j]] without materialising feats[knn] ([N,40,35]); HIP forward and
+    # atomics backward (ops.aggregate), atts detached as in the reference (occnerf_mlp.py:124)
+    agg = ops.aggregate(feats, knn_idxs.reshape(N, -1), atts.detach().reshape(N, -1))
 
     enc = h
     z = torch.cat([agg, var, enc], dim=-1).float()

@@ -635,3 +635,20 @@ def test_gen_rays(ops, tag):
     assert fr['rays'].shape == (2, R, 3) and fr['near'].shape == (R, 1) and fr['far'].shape == (R, 1)
     assert np.abs(fr['rays'][1].cpu().numpy() - g[f'{tag}.rays_d'][want_mask]).max() <= 1e-6
     assert np.array_equal(fr['ray_mask'].cpu().numpy(), want_mask)
+
+
+def test_aggregate_autograd(ops):
+    """HIP neighbour aggregation (training path) against torch's gather + sum and its autograd."""
+    torch.manual_seed(0)
+    P, N, K, Fd = 6890, 3001, 40, 35
+    feats = torch.randn(P, Fd, device=DEV, requires_grad=True)
+    knn = torch.randint(0, P, (N, K), device=DEV, dtype=torch.int32)
+    knn[:, :5] = 7                                                  # heavy duplicates -> contended atomics
+    atts = torch.softmax(torch.randn(N, K, device=DEV), dim=1)
+    want = (atts[..., None] * feats[knn.long()]).sum(1)
+    got = ops.aggregate(feats, knn, atts)
+    assert (got - want).abs().max().item() <= 2e-6
+    gout = torch.randn(N, Fd, device=DEV)
+    gw, = torch.autograd.grad(want, feats, gout, retain_graph=True)
+    gg, = torch.autograd.grad(got, feats, gout)
+    assert (gg - gw).abs().max().item() <= 1e-4 * gw.abs().max().item()
