@@ -210,12 +210,15 @@ int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs
 
 /* Differentiable neighbour aggregation of the training path (occnerf_mlp.py:86-126 simple_agg with the
  * gather of :176-178): agg[n,:] = sum_j atts[n,j] * feats[knn[n,j],:] for feats[P,F] (F <= 64), knn[N,K],
- * atts[N,K] (detached in the reference), and its gradient scattered into grad_feats[P,F] (accumulated: zero
- * it first) with fp32 atomics.  Replaces torch's feats[knn] materialisation and index_put backward. */
+ * atts[N,K] (detached in the reference).  Backward: partial[W,P,F] with W = occnerf_agg_backward_slices(N);
+ * every element is written, grad_feats = partial.sum(0).  Workgroups own (sample slice, point tile) pairs
+ * and accumulate in LDS -- no global atomics.  Replaces torch's feats[knn] materialisation and its index_put
+ * backward. */
 int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *knn, const float *atts, int64_t N, int32_t K,
                         float *agg, void *stream);
+int32_t occnerf_agg_backward_slices(int64_t N);
 int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t *knn, const float *atts, int64_t N,
-                         int32_t K, float *grad_feats, void *stream);
+                         int32_t K, int32_t P, float *partial, void *stream);
 
 /* Canonical MLP weights -> MFMA operand order.  h_W/h_b: HOST arrays of the 10 device
  * weight/bias pointers in module order: pts_linears.{0,2,4,6}, geo_linear.0,

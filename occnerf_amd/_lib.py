@@ -38,7 +38,8 @@ SIGNATURES = {
     'occnerf_point_sdf': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     'occnerf_gen_rays': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_agg_forward': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
-    'occnerf_agg_backward': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
+    'occnerf_agg_backward_slices': (_i32, [_i64]),
+    'occnerf_agg_backward': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     'occnerf_point_table_stride': (_i32, []),
     'occnerf_point_table': (C.c_int, [_vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _u32, _f32, _u32, _vp,
                                        _vp]),

@@ -34,27 +34,47 @@ __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restric
     if (lane < F) agg[n * F + lane] = acc;
 }
 
-__global__ __launch_bounds__(256) void agg_backward_kernel(const float *__restrict__ grad_agg, int F,
-                                                           const int32_t *__restrict__ knn,
-                                                           const float *__restrict__ atts, int64_t N, int K,
-                                                           float *__restrict__ grad_feats) {
-    const int lane = threadIdx.x & 63;
-    const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (n >= N) return;
-    const int32_t *id = knn + n * K;
-    const float *w = atts + n * K;
-    const float g = lane < F ? grad_agg[n * F + lane] : 0.0f;
-    for (int j0 = 0; j0 < K; j0 += 64) {
-        const int jj = j0 + lane;
-        const int my_id = jj < K ? id[jj] : 0;
-        const float my_w = jj < K ? w[jj] : 0.0f;
-        const int cnt = K - j0 < 64 ? K - j0 : 64;
-        for (int j = 0; j < cnt; j++) {
-            const int p = __shfl(my_id, j);
-            const float wj = __shfl(my_w, j);
-            if (lane < F) atomicAdd(grad_feats + (size_t)p * F + lane, __fmul_rn(wj, g));
+// Backward.  Global fp32 atomics are memory-side operations on this part (~20 G/s even on a 1 MB table:
+// 54 ms for one training batch), so the scatter is organised by OWNERSHIP instead: workgroup (w, tile) owns
+// the gradient rows of kTilePoints consecutive points for the w-th slice of the samples, keeps them in LDS,
+// scans its samples (one wave per sample: the 40 ids in 40 lanes, ballot of the ones in the tile, then one
+// LDS atomic instruction per hit with lane c = column c) and finally stores the tile to partial[w] with plain
+// writes; the caller sums the W partial tables.  No global atomics.
+constexpr int kAggTileFloats = 36864;            // 144 KiB of LDS
+
+__global__ __launch_bounds__(1024) void agg_backward_tiled_kernel(const float *__restrict__ grad_agg, int F,
+                                                                  const int32_t *__restrict__ knn,
+                                                                  const float *__restrict__ atts, int64_t N, int K,
+                                                                  int P, int tile_points, int64_t samples_per_slice,
+                                                                  float *__restrict__ partial /*[W][P][F]*/) {
+    __shared__ float s_g[kAggTileFloats];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int tile0 = blockIdx.y * tile_points;
+    const int tile_n = P - tile0 < tile_points ? P - tile0 : tile_points;
+    for (int i = threadIdx.x; i < tile_n * F; i += blockDim.x) s_g[i] = 0.0f;
+    __syncthreads();
+    const int64_t n0 = (int64_t)blockIdx.x * samples_per_slice;
+    const int64_t n1 = n0 + samples_per_slice < N ? n0 + samples_per_slice : N;
+    for (int64_t n = n0 + wave; n < n1; n += nwaves) {
+        const float g = lane < F ? grad_agg[n * F + lane] : 0.0f;
+        for (int j0 = 0; j0 < K; j0 += 64) {
+            const int jj = j0 + lane;
+            const int my_id = jj < K ? knn[n * K + jj] : -1;
+            const float my_w = jj < K ? atts[n * K + jj] : 0.0f;
+            const unsigned rel = (unsigned)(my_id - tile0);
+            unsigned long long hits = __builtin_amdgcn_ballot_w64(jj < K && rel < (unsigned)tile_n);
+            while (hits) {
+                const int j = __builtin_ctzll(hits);                       // wave-uniform: v_readlane, no LDS trip
+                hits &= hits - 1;
+                const int p = __builtin_amdgcn_readlane(my_id, j) - tile0;
+                const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
+                if (lane < F) atomicAdd(&s_g[p * F + lane], __fmul_rn(wj, g));
+            }
         }
     }
+    __syncthreads();
+    float *dst = partial + ((size_t)blockIdx.x * P + tile0) * F;
+    for (int i = threadIdx.x; i < tile_n * F; i += blockDim.x) dst[i] = s_g[i];
 }
 
 }  // namespace occ
@@ -72,15 +92,23 @@ OCC_API int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *kn
     return check_launch("agg_forward");
 }
 
+OCC_API int32_t occnerf_agg_backward_slices(int64_t N) {
+    // sample slices W: with ceil(P / tile) point tiles this gives a few hundred workgroups
+    int64_t w = (N + 16383) / 16384;
+    return (int32_t)(w < 1 ? 1 : (w > 48 ? 48 : w));
+}
+
 OCC_API int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t *knn, const float *atts, int64_t N,
-                                 int32_t K, float *grad_feats, void *stream) {
+                                 int32_t K, int32_t P, float *partial, void *stream) {
     using namespace occ;
     if (N <= 0) return 0;
-    OCC_REQUIRE(grad_agg && knn && atts && grad_feats, "agg_backward: null argument");
-    OCC_REQUIRE(F >= 1 && F <= 64 && K >= 1, "agg_backward: F=%d (1..64), K=%d", F, K);
-    const int64_t blocks = (N + 3) / 4;
-    OCC_REQUIRE(blocks < (1ll << 31), "agg_backward: N too large");
-    hipLaunchKernelGGL(agg_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), grad_agg, F, knn,
-                       atts, N, K, grad_feats);
+    OCC_REQUIRE(grad_agg && knn && atts && partial, "agg_backward: null argument");
+    OCC_REQUIRE(F >= 1 && F <= 64 && K >= 1 && P >= 1, "agg_backward: F=%d (1..64), K=%d, P=%d", F, K, P);
+    const int W = occnerf_agg_backward_slices(N);
+    const int tile_points = kAggTileFloats / F < 1024 ? kAggTileFloats / F : 1024;
+    const int tiles = (P + tile_points - 1) / tile_points;
+    const int64_t per_slice = (N + W - 1) / W;
+    hipLaunchKernelGGL(agg_backward_tiled_kernel, dim3(W, tiles), dim3(1024), 0, as_stream(stream), grad_agg, F, knn,
+                       atts, N, K, P, tile_points, per_slice, partial);
     return check_launch("agg_backward");
 }

@@ -401,13 +401,14 @@ def agg_forward(feats, knn, atts):
 def agg_backward(grad_agg, knn, atts, P):
     N, K = knn.shape
     F = grad_agg.shape[1]
-    grad_feats = torch.zeros(P, F, device=grad_agg.device, dtype=torch.float32)
+    W = int(_lib.lib().occnerf_agg_backward_slices(N))
+    partial = torch.empty(W, P, F, device=grad_agg.device, dtype=torch.float32)
     with _guard(grad_agg):
         rc = _lib.lib().occnerf_agg_backward(_chk(grad_agg, torch.float32, 'grad_agg'), int(F),
                                              _chk(knn, torch.int32, 'knn'), _chk(atts, torch.float32, 'atts'), N,
-                                             int(K), grad_feats.data_ptr(), _stream(grad_agg))
+                                             int(K), int(P), partial.data_ptr(), _stream(grad_agg))
     _lib.check(rc, 'agg_backward')
-    return grad_feats
+    return partial.sum(0)
 
 
 class _Aggregate(torch.autograd.Function):
