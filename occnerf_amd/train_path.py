@@ -78,7 +78,9 @@ def canonical_mlp_torch(cm, xyz, knn_idxs, net, knn_base, point_sdf):
     normals = net.point_norms.to(xyz.device)[idx0]                               # float64
     with torch.no_grad():
         direction = xyz[:, None, :] - knn_points
-        inside = (torch.einsum('ijk,ijk->ij', direction.double(), normals.double()) < 0).sum(1) > k * 0.5
+        # row-wise fp64 dot products (the reference's einsum 'ijk,ijk->ij' runs as a batched fp64 GEMM: 13 ms
+        # per step here); only the sign is used
+        inside = ((direction.double() * normals.double()).sum(-1) < 0).sum(1) > k * 0.5
         dist = torch.norm(direction, dim=-1).mean(1, keepdim=True)
         dist = torch.where(inside[:, None], -dist, dist)
         normed = torch.clamp((dist + 0.2) / 0.5, 0.0, 1.0)
