@@ -129,100 +129,56 @@ __global__ __launch_bounds__(256) void grid_forward_kernel(
 }
 
 // gridencoder.cu:248-340.  One thread per (sample, level); all C channels of a corner are
-// added by the same thread (C <= 8), fp32 atomics into the zero-initialised gradient table.
-//
-// COMBINE: on coarse levels many of the 256 consecutive samples of a workgroup (neighbours along a ray) fall
-// into the same cells, and same-address L2 atomics serialise (a 786 K-sample batch spent 170 ms here).  The
-// workgroup first adds its contributions into a small open-addressing table in LDS (ds atomics), then
-// flushes one global atomic per distinct cell; a contribution that finds the table full goes straight to
-// global memory, so the result is the same sum in any case.  The host uses it for levels whose resolution
-// is small against the sample spacing (grid_combine_levels) and plain atomics for the fine ones.
-constexpr uint32_t kCombineSlots = 2048;
-
-template <uint32_t D, uint32_t C, bool COMBINE>
+// added by the same thread (C <= 8), fp32 atomics into the zero-initialised gradient table.  (Used for small
+// batches and the general D/C/gridtype cases; large D = 4, C = 2 batches take the tiled kernel below.)
+template <uint32_t D, uint32_t C>
 __global__ __launch_bounds__(256) void grid_backward_kernel(
     const float *__restrict__ grad, const float *__restrict__ inputs,
     const int32_t *__restrict__ offsets, float *__restrict__ grad_grid, uint32_t B, uint32_t L,
-    GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t level0) {
-    __shared__ uint32_t s_key[COMBINE ? kCombineSlots : 1];
-    __shared__ float s_val[COMBINE ? kCombineSlots * C : 1];
-    const uint32_t level = level0 + blockIdx.y;
-    if (COMBINE) {
-        for (uint32_t i = threadIdx.x; i < kCombineSlots; i += blockDim.x) s_key[i] = 0xFFFFFFFFu;
-        for (uint32_t i = threadIdx.x; i < kCombineSlots * C; i += blockDim.x) s_val[i] = 0.0f;
-        __syncthreads();
-    }
+    GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = b < B;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
     float *gg = grad_grid + (size_t)(uint32_t)offsets[level] * C;
+    const float *x = inputs + (size_t)b * D;
+    const float *g = grad + ((size_t)level * B + b) * C;
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const float scale = lv.scale[level];
     const uint32_t resolution = lv.resolution[level];
 
     float pos[D];
     uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float xd = x[d];
+        if (xd < 0.f || xd > 1.f) return;  // gradient stays zero
+        pos[d] = __fmaf_rn(xd, scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= fl;
+        if (interp == 1)
+            pos[d] = __fmul_rn(__fmul_rn(pos[d], pos[d]), __fsub_rn(3.0f, __fmul_rn(2.0f, pos[d])));
+    }
     float gc[C];
-    if (active) {
-        const float *x = inputs + (size_t)b * D;
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) gc[ch] = g[ch];
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1.f;
+        uint32_t pl[D];
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) {
-            const float xd = x[d];
-            if (xd < 0.f || xd > 1.f) active = false;  // gradient stays zero
-            pos[d] = __fmaf_rn(xd, scale, align_corners ? 0.0f : 0.5f);
-            const float fl = floorf(pos[d]);
-            pg[d] = (uint32_t)fl;
-            pos[d] -= fl;
-            if (interp == 1)
-                pos[d] = __fmul_rn(__fmul_rn(pos[d], pos[d]), __fsub_rn(3.0f, __fmul_rn(2.0f, pos[d])));
-        }
-        const float *g = grad + ((size_t)level * B + b) * C;
-#pragma unroll
-        for (uint32_t ch = 0; ch < C; ch++) gc[ch] = g[ch];
-    }
-    if (active) {
-#pragma unroll
-        for (uint32_t idx = 0; idx < (1u << D); idx++) {
-            float w = 1.f;
-            uint32_t pl[D];
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) {
-                if ((idx & (1u << d)) == 0) {
-                    w = __fmul_rn(w, __fsub_rn(1.f, pos[d]));
-                    pl[d] = pg[d];
-                } else {
-                    w = __fmul_rn(w, pos[d]);
-                    pl[d] = pg[d] + 1;
-                }
-            }
-            const uint32_t cell = grid_index<D>(gridtype, align_corners, hashmap_size, resolution, pl);
-            bool done = false;
-            if (COMBINE) {
-                uint32_t h = (cell * 2654435761u) >> 21;                    // 11 bits = kCombineSlots
-                for (int probe = 0; probe < 16 && !done; probe++) {
-                    const uint32_t k = atomicCAS(&s_key[h], 0xFFFFFFFFu, cell);
-                    if (k == 0xFFFFFFFFu || k == cell) {
-#pragma unroll
-                        for (uint32_t ch = 0; ch < C; ch++) atomicAdd(&s_val[h * C + ch], __fmul_rn(w, gc[ch]));
-                        done = true;
-                    }
-                    h = (h + 1) & (kCombineSlots - 1);
-                }
-            }
-            if (!done) {
-#pragma unroll
-                for (uint32_t ch = 0; ch < C; ch++) atomicAdd(&gg[cell * C + ch], __fmul_rn(w, gc[ch]));
+            if ((idx & (1u << d)) == 0) {
+                w = __fmul_rn(w, __fsub_rn(1.f, pos[d]));
+                pl[d] = pg[d];
+            } else {
+                w = __fmul_rn(w, pos[d]);
+                pl[d] = pg[d] + 1;
             }
         }
-    }
-    if (COMBINE) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < kCombineSlots; i += blockDim.x) {
-            const uint32_t cell = s_key[i];
-            if (cell != 0xFFFFFFFFu) {
+        const uint32_t index = grid_index<D>(gridtype, align_corners, hashmap_size, resolution, pl) * C;
 #pragma unroll
-                for (uint32_t ch = 0; ch < C; ch++) atomicAdd(&gg[cell * C + ch], s_val[i * C + ch]);
-            }
-        }
+        for (uint32_t ch = 0; ch < C; ch++) atomicAdd(&gg[index + ch], __fmul_rn(w, gc[ch]));
     }
 }
 
@@ -358,21 +314,11 @@ template <uint32_t D>
 int launch_backward_c(uint32_t C, const float *grad, const float *in, const int32_t *off, float *gg,
                       uint32_t B, uint32_t L, const GridLevels &lv, const float *dy, float *gi,
                       uint32_t gt, bool ac, uint32_t interp, hipStream_t st) {
-    const dim3 block(256);
+    const dim3 grid((B + 255) / 256, L), block(256);
     const dim3 grid_in((B * D + 255) / 256);
-    // levels [0, lc) combine in LDS first: coarse enough that a workgroup's 256 consecutive samples share cells
-    // (resolution <= 256 cells per unit: consecutive ray samples are ~0.005 apart in encoder space); only
-    // worth it for batches large enough to contend
-    uint32_t lc = 0;
-    if (B >= 65536)
-        while (lc < L && lv.resolution[lc] <= 256) lc++;
 #define OCC_BWD(CC)                                                                                   \
-    if (lc > 0)                                                                                       \
-        hipLaunchKernelGGL((grid_backward_kernel<D, CC, true>), dim3((B + 255) / 256, lc), block, 0, st, grad, in, off, \
-                           gg, B, L, lv, gt, ac, interp, 0u);                                         \
-    if (lc < L)                                                                                       \
-        hipLaunchKernelGGL((grid_backward_kernel<D, CC, false>), dim3((B + 255) / 256, L - lc), block, 0, st, grad, in, \
-                           off, gg, B, L, lv, gt, ac, interp, lc);                                    \
+    hipLaunchKernelGGL((grid_backward_kernel<D, CC>), grid, block, 0, st, grad, in, off, gg, B, L, lv, \
+                       gt, ac, interp);                                                               \
     if (dy) hipLaunchKernelGGL((grid_input_backward_kernel<D, CC>), grid_in, block, 0, st, grad, dy, gi, B, L);
     switch (C) {
         case 1: OCC_BWD(1) break;
