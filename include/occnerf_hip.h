@@ -148,17 +148,16 @@ int occnerf_msknn(const float *xyz, int64_t N, const float *points, const int32_
  * Layout (built by the host once per model, occnerf_amd/geometry.py::build_knn_clusters):
  * points[M,4] = every scale but the coarsest stored cluster by cluster (cluster = nearest
  * coarsest-scale point), then the coarsest scale in original order at rows
- * h_coarse_rows[0..1); segments padded to multiples of 4 rows with +inf points; .w = the
- * point's original row within its scale as int bits (reported, and the tie-break key);
- * index_map = base-point index of every original row, scales concatenated, h_orig_begin[s]
- * the offset of scale s; centers[ncl,4]; cluster_ranges[nscale-1,ncl,2] row ranges into
- * points; cluster_radius[nscale-1,ncl] >= max |p - center| per cluster. */
+ * h_coarse_rows[0..1); segments padded to multiples of 4 rows with +inf points; .w (int bits) =
+ * original row within the scale << 16 | base-point index: the row is the tie-break key among equal
+ * distances, the base index (< 65536) is what knn_idxs reports; centers[ncl,4];
+ * cluster_ranges[nscale-1,ncl,2] row ranges into points; cluster_radius[nscale-1,ncl] >=
+ * max |p - center| per cluster. */
 int occnerf_msknn_clustered(const float *xyz, int64_t n_rays, int32_t samples_per_ray,
-                            const float *points, const int32_t *index_map, const float *centers,
+                            const float *points, const float *centers,
                             const int32_t *cluster_ranges, const float *cluster_radius, int32_t ncl,
-                            const int32_t *h_coarse_rows, const int32_t *h_orig_begin,
-                            const int32_t *h_seed_from_coarser, int32_t nscale, int32_t *knn_idxs,
-                            void *stream);
+                            const int32_t *h_coarse_rows, const int32_t *h_seed_from_coarser,
+                            int32_t nscale, int32_t *knn_idxs, void *stream);
 
 /* Plain exact kNN for small problems (k <= 16): idx[nq,k] rows of s, ascending.
  * Used for the per-point k=3 search of network.py:265-269 and the k=10 visibility update

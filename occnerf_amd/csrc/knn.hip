@@ -200,13 +200,12 @@ __device__ __forceinline__ void consider_lex(KBest64 &b, float &thr, float &sb, 
 struct ClusteredScales {
     int nscale, ncl;
     int coarse_begin, coarse_end;   // rows of the coarsest scale (original order, padded to 4)
-    int orig_begin[4];              // offset of each scale inside index_map (original row order)
     int seed[4];
 };
 
 __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     const float *__restrict__ xyz, int64_t n_rays, int S, const float4 *__restrict__ points,
-    const int32_t *__restrict__ index_map, const float4 *__restrict__ centers,
+    const float4 *__restrict__ centers,
     const int2 *__restrict__ ranges /*[nscale-1][ncl]*/, const float *__restrict__ radius /*[nscale-1][ncl]*/,
     ClusteredScales sc, int32_t *__restrict__ knn_idxs) {
     const int lane = threadIdx.x & 63;
@@ -257,12 +256,19 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
             OCC_PTL(p2, 0) OCC_PTL(p2, 1) OCC_PTL(p3, 0) OCC_PTL(p3, 1)                     \
         }                                                                                   \
     }
+    /* .w of a point = original row << 16 | base-point index: the key's low word orders ties by row and   \
+       carries the reported index, so no index_map gather; 10 indices = 40 contiguous bytes = 3 stores */   \
 #define OCC_EMIT(L)                                                                         \
     _Pragma("unroll") for (int a = 0; a < kQ; a++) {                                        \
         if (live[a]) {                                                                      \
+            struct __attribute__((packed, aligned(4))) I4 { int v[4]; };                    \
+            struct __attribute__((packed, aligned(4))) I2 { int v[2]; };                    \
             int32_t *out = knn_idxs + (qi[a] * sc.nscale + (L)) * kK;                       \
-            _Pragma("unroll") for (int p = 0; p < kK; p++)                                  \
-                out[p] = index_map[sc.orig_begin[(L)] + key_row(best[a].k[p])];                      \
+            int r_[kK];                                                                     \
+            _Pragma("unroll") for (int p = 0; p < kK; p++) r_[p] = key_row(best[a].k[p]) & 0xFFFF; \
+            *reinterpret_cast<I4 *>(out) = I4{{r_[0], r_[1], r_[2], r_[3]}};                \
+            *reinterpret_cast<I4 *>(out + 4) = I4{{r_[4], r_[5], r_[6], r_[7]}};            \
+            *reinterpret_cast<I2 *>(out + 8) = I2{{r_[8], r_[9]}};                          \
         }                                                                                   \
     }
 
@@ -429,16 +435,16 @@ OCC_API int occnerf_msknn(const float *xyz, int64_t N, const float *points,
 }
 
 OCC_API int occnerf_msknn_clustered(const float *xyz, int64_t n_rays, int32_t samples_per_ray,
-                                    const float *points, const int32_t *index_map,
+                                    const float *points,
                                     const float *centers, const int32_t *cluster_ranges,
                                     const float *cluster_radius, int32_t ncl,
-                                    const int32_t *h_coarse_rows, const int32_t *h_orig_begin,
+                                    const int32_t *h_coarse_rows,
                                     const int32_t *h_seed_from_coarser, int32_t nscale,
                                     int32_t *knn_idxs, void *stream) {
     using namespace occ;
     if (n_rays <= 0 || samples_per_ray <= 0) return 0;
-    OCC_REQUIRE(xyz && points && index_map && centers && cluster_ranges && cluster_radius && h_coarse_rows &&
-                    h_orig_begin && knn_idxs, "msknn_clustered: null argument");
+    OCC_REQUIRE(xyz && points && centers && cluster_ranges && cluster_radius && h_coarse_rows && knn_idxs,
+                "msknn_clustered: null argument");
     OCC_REQUIRE(nscale >= 2 && nscale <= 4, "msknn_clustered: nscale=%d unsupported (2..4)", nscale);
     OCC_REQUIRE(ncl >= 1, "msknn_clustered: ncl=%d", ncl);
     ClusteredScales sc;
@@ -449,14 +455,13 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, int64_t n_rays, int32_t sa
     OCC_REQUIRE(sc.coarse_begin % 4 == 0 && (sc.coarse_end - sc.coarse_begin) % 4 == 0 &&
                     sc.coarse_end - sc.coarse_begin >= kK, "msknn_clustered: bad coarse row range");
     for (int l = 0; l < 4; l++) {
-        sc.orig_begin[l] = l < nscale ? h_orig_begin[l] : 0;
         sc.seed[l] = (l < nscale && h_seed_from_coarser) ? h_seed_from_coarser[l] : 0;
     }
     const int64_t tiles = ((n_rays + 63) / 64) * ((samples_per_ray + 3) / 4);
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > (int64_t)kNumCU * 16) blocks = (int64_t)kNumCU * 16;
     hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz,
-                       n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points), index_map,
+                       n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points),
                        reinterpret_cast<const float4 *>(centers), reinterpret_cast<const int2 *>(cluster_ranges),
                        cluster_radius, sc, knn_idxs);
     return check_launch("msknn_clustered");

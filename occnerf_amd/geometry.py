@@ -32,12 +32,11 @@ def build_knn_clusters(point_base, scale_indices):
     scale in the reference's order, network.py:239-241).  The points of every scale but the
     coarsest are grouped by their nearest coarsest-scale point and stored cluster by cluster
     (ascending original row inside a cluster), each segment padded to a multiple of 4 rows
-    with +inf points; float4.w carries the point's ORIGINAL row within its scale (as int
-    bits), which is what the search reports and breaks distance ties on.
+    with +inf points; float4.w carries (as int bits) ORIGINAL row within the scale << 16 | base-point
+    index: the row breaks distance ties, the base index is what the search reports.
 
-    Returns dict of numpy arrays: points[M,4] f32, index_map[sum sizes] i32 (original order),
-    centers[ncl,4] f32, ranges[nscale-1,ncl,2] i32, radius[nscale-1,ncl] f32,
-    coarse_rows (begin, end), orig_begin[nscale]."""
+    Returns dict of numpy arrays: points[M,4] f32, centers[ncl,4] f32, ranges[nscale-1,ncl,2] i32,
+    radius[nscale-1,ncl] f32, coarse_rows (begin, end)."""
     base = np.ascontiguousarray(point_base, dtype=np.float32)
     sets = [np.asarray(s, dtype=np.int64) for s in scale_indices]
     nscale = len(sets)
@@ -48,14 +47,16 @@ def build_knn_clusters(point_base, scale_indices):
     radius = np.zeros((nscale - 1, ncl), np.float32)
     cursor = 0
 
-    def emit(pts, orig_rows):
+    assert base.shape[0] < 65536 and max(len(t) for t in sets) < 32768, 'row << 16 | base index must fit 31 bits'
+
+    def emit(pts, orig_rows, base_rows):
         nonlocal cursor
         n = len(orig_rows)
         pad = (-n) % 4
         blk = np.full((n + pad, 4), np.inf, np.float32)
         blk[:n, :3] = pts
         w = np.zeros(n + pad, np.int32)
-        w[:n] = orig_rows
+        w[:n] = (np.asarray(orig_rows, np.int64) << 16) | np.asarray(base_rows, np.int64)
         blk[:, 3] = w.view(np.float32)
         rows.append(blk)
         begin = cursor
@@ -71,12 +72,10 @@ def build_knn_clusters(point_base, scale_indices):
             if len(members) == 0:
                 ranges[l, k] = (cursor, cursor)
                 continue
-            ranges[l, k] = emit(pts[members], members)
+            ranges[l, k] = emit(pts[members], members, sets[l][members])
             radius[l, k] = np.float32(dmin[members].max() * (1 + 1e-6) + 1e-7)
-    coarse = emit(base[cidx], np.arange(ncl))
+    coarse = emit(base[cidx], np.arange(ncl), cidx)
     centers = np.zeros((ncl, 4), np.float32)
     centers[:, :3] = base[cidx]
-    orig_begin = np.cumsum([0] + [len(s) for s in sets[:-1]]).astype(np.int32)
-    return {'points': np.concatenate(rows, 0), 'index_map': np.concatenate(sets).astype(np.int32),
-            'centers': centers, 'ranges': ranges, 'radius': radius,
-            'coarse_rows': np.array(coarse, np.int32), 'orig_begin': orig_begin, 'ncl': ncl}
+    return {'points': np.concatenate(rows, 0), 'centers': centers, 'ranges': ranges, 'radius': radius,
+            'coarse_rows': np.array(coarse, np.int32), 'ncl': ncl}

@@ -231,17 +231,16 @@ def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
 
 def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser):
     """cl: device-side cluster layout (dict, see Network._context / geometry.build_knn_clusters)."""
-    nscale = len(cl['orig_begin'])
+    nscale = int(cl['ranges'].shape[0]) + 1
     out = torch.empty(n_rays * S, nscale, 10, device=xyz.device, dtype=torch.int32)
     _kc, pc = _host_i32(cl['coarse_rows'])
-    _ko, po = _host_i32(cl['orig_begin'])
     _ks, ps = _host_i32(seed_from_coarser)
     with _guard(xyz):
         rc = _lib.lib().occnerf_msknn_clustered(
             _chk(xyz, torch.float32, 'xyz'), int(n_rays), int(S), _chk(cl['points'], torch.float32, 'points'),
-            _chk(cl['index_map'], torch.int32, 'index_map'), _chk(cl['centers'], torch.float32, 'centers'),
-            _chk(cl['ranges'], torch.int32, 'cluster_ranges'), _chk(cl['radius'], torch.float32, 'cluster_radius'),
-            int(cl['ncl']), pc, po, ps, nscale, out.data_ptr(), _stream(xyz))
+            _chk(cl['centers'], torch.float32, 'centers'), _chk(cl['ranges'], torch.int32, 'cluster_ranges'),
+            _chk(cl['radius'], torch.float32, 'cluster_radius'), int(cl['ncl']), pc, ps, nscale, out.data_ptr(),
+            _stream(xyz))
     _lib.check(rc, 'msknn_clustered')
     return out
 
