@@ -168,6 +168,25 @@ def main():
         net.cfg.mlp_precision = 'fp32'
         net.invalidate_cache()
 
+    # every sample evaluated (cfg.skip_empty_samples off): same pixels bit for bit, reported beside the headline
+    full = None
+    if world == 1 and not args.no_alt:
+        ops.canonical_mlp = real_mlp
+        net.cfg.skip_empty_samples = False
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - tf
+        full = {'skip_empty_samples': False, 'value': R * args.steps / dtf, 'unit': 'rays/s',
+                'ms_per_step': dtf / args.steps * 1e3,
+                'note': 'all R x 128 samples through every stage; the headline drops the samples whose motion-weight '
+                        'sum is exactly 0 (alpha is multiplied by it), with bit-identical rgb/alpha/depth'}
+        net.cfg.skip_empty_samples = True
+
     if rank == 0:
         ms = [e0.elapsed_time(e1) for e0, e1, _ in mlp_events]
         nsmp = [n for _, _, n in mlp_events]
@@ -182,6 +201,8 @@ def main():
                                    'non-rigid motion on, seeded random-init checkpoint; synthetic SMPL-like body '
                                    f'and camera; {R} rays hit the body bbox (ray_mask), one frame per GPU per step',
                        'rays_per_frame': R, 'samples_per_ray': SPP, 'image': [IMG, IMG],
+                       'samples_evaluated_per_frame': float(np.mean(nsmp)),
+                       'skip_empty_samples': bool(net.cfg.get('skip_empty_samples', True)),
                        'parallelism': f'frames x{world} (rays sharded by frame), RCCL gather to rank 0'},
             'roofline': {'bound': 'mfma', 'kernel': 'occ::m16::canonical_mlp_lds_kernel (fp32 MFMA 16x16x4, LDS-staged weights)',
                          'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12, 'unit': 'TFLOP/s',
@@ -193,6 +214,8 @@ def main():
         }
         if alt is not None:
             line['alt'] = alt
+        if full is not None:
+            line['all_samples'] = full
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(ctx, frame, args.cpu_rays)
         print(json.dumps(line))

@@ -152,8 +152,10 @@ int occnerf_msknn(const float *xyz, int64_t N, const float *points, const int32_
  * original row within the scale << 16 | base-point index: the row is the tie-break key among equal
  * distances, the base index (< 65536) is what knn_idxs reports; centers[ncl,4];
  * cluster_ranges[nscale-1,ncl,2] row ranges into points; cluster_radius[nscale-1,ncl] >=
- * max |p - center| per cluster. */
-int occnerf_msknn_clustered(const float *xyz, int64_t n_rays, int32_t samples_per_ray,
+ * max |p - center| per cluster.  mask (nullable) [n_rays * samples_per_ray]: samples whose mask is
+ * exactly 0 (motion-weight sum, network.py:330: their alpha is multiplied by it) are skipped and their
+ * knn_idxs rows left unwritten. */
+int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t n_rays, int32_t samples_per_ray,
                             const float *points, const float *centers,
                             const int32_t *cluster_ranges, const float *cluster_radius, int32_t ncl,
                             const int32_t *h_coarse_rows, const int32_t *h_seed_from_coarser,
@@ -197,14 +199,17 @@ int occnerf_point_table(const double *knn_base, const float *point_sdf, const fl
  * Two optional inputs serve callers that hold the reference's *gathered* CanonicalMLP
  * arguments instead of per-point arrays: geo_idxs[N,10] (rows of point_base/normals to use
  * for the geometry prelude instead of knn_idxs[:,0,:]) and att_in[N,nscale*10] (visibility
- * counts already gathered, used instead of counter[knn_idxs]); NULL for the normal path. */
+ * counts already gathered, used instead of counter[knn_idxs]); NULL for the normal path.
+ * rows (nullable, renderer's path only): a compact list of N sample indices into xyz / knn_idxs -- the
+ * samples that can contribute to their pixel (motion-weight sum != 0); output row m then belongs to
+ * sample rows[m]. */
 int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs, int32_t nscale,
                             const float *point_base, const double *normals,
                             const double *unit_normals, const float *counter,
                             const float *table, float bound, float two_bound,
                             const float *embeddings, const int32_t *offsets,
                             const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
-                            const int32_t *geo_idxs, const float *att_in,
+                            const int32_t *geo_idxs, const float *att_in, const int32_t *rows,
                             float *mlp_in, float *raw, float *enc_in, void *stream);
 
 /* Differentiable neighbour aggregation of the training path (occnerf_mlp.py:86-126 simple_agg with the

@@ -31,7 +31,7 @@ SIGNATURES = {
     'occnerf_nonrigid_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_nonrigid_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_msknn': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
-    'occnerf_msknn_clustered': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    'occnerf_msknn_clustered': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     'occnerf_knn_small': (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'occnerf_unit_normals': (C.c_int, [_vp, _i32, _vp, _vp]),
     'occnerf_point_sdf': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
@@ -43,7 +43,7 @@ SIGNATURES = {
     'occnerf_point_table': (C.c_int, [_vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _u32, _f32, _u32, _vp,
                                        _vp]),
     'occnerf_sample_features': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp,
-                                           _vp, _vp, _u32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                           _vp, _vp, _u32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp_packed_floats': (_i64, []),
     'occnerf_canonical_mlp_pack': (C.c_int, [_vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),

@@ -93,6 +93,7 @@ _DEFAULTS = {
     # 'fp32': exact fp32 MFMA (default, the parity/benchmark path); 'bf16x3': split-bf16 MFMA,
     # ~3x faster MLP, raw logits within ~1e-5 of fp32
     'mlp_precision': 'fp32',
+    'skip_empty_samples': True,      # drop samples whose motion-weight sum is exactly 0 (identical pixels)
     'device_rays': True,             # run.py: generate the frame's ray batch on the GPU (occnerf_amd/rays.py)
     'ray_patch_order': True,         # render rays in Morton-ordered pixel patches (any order is exact)
     'knn_culling': True,             # cluster-culled exact kNN (False: brute force)

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
     const float *__restrict__ point_base, const double *__restrict__ normals,
     const double *__restrict__ unit, const float *__restrict__ counter,
     const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
-    LevelRecs levels, FeatParams prm,
+    LevelRecs levels, FeatParams prm, const int32_t *__restrict__ rows /*nullable: compact list of samples*/,
     float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
     constexpr int NK = 4 * kKnn;                       // 40 neighbours over 4 scales
     const int g = threadIdx.x & 7;
@@ -327,7 +327,8 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
     for (int64_t it = 0; it < iters; it++) {
         const int64_t i_raw = group0 + it * ngroups;
         const bool live = i_raw < N;
-        const int64_t i = live ? i_raw : N - 1;         // keep every lane in the shuffles
+        const int64_t o = live ? i_raw : N - 1;         // output row; keep every lane in the shuffles
+        const int64_t i = rows ? (int64_t)rows[o] : o;  // input row (sample) in xyz / knn_idxs
         const int32_t *id = knn_idxs + i * NK;
         struct __attribute__((packed, aligned(4))) F3 { float v[3]; };
         const F3 pq = *reinterpret_cast<const F3 *>(xyz + i * 3);               // one 12-byte load
@@ -389,10 +390,10 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
 #pragma unroll
         for (int c = 0; c < 3; c++) x[c] = (float)__ddiv_rn(num[c], den);
         x[3] = nd;
-        float *out = mlp_in + i * 68;
+        float *out = mlp_in + o * 68;
         if (live && g == 0) {
-            raw[i * 5 + 4] = dist;
-            if (enc_in_out) *reinterpret_cast<float4 *>(enc_in_out + i * 4) = make_float4(x[0], x[1], x[2], x[3]);
+            raw[o * 5 + 4] = dist;
+            if (enc_in_out) *reinterpret_cast<float4 *>(enc_in_out + o * 4) = make_float4(x[0], x[1], x[2], x[3]);
         }
 
         // ---- hash encoding: lane g -> levels 2g, 2g+1 -> features 4g..4g+3 ----
@@ -546,8 +547,8 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                                     const float *embeddings, const int32_t *offsets,
                                     const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
                                     const int32_t *geo_idxs,
-                                    const float *att_in, float *mlp_in, float *raw, float *enc_in,
-                                    void *stream) {
+                                    const float *att_in, const int32_t *rows, float *mlp_in, float *raw,
+                                    float *enc_in, void *stream) {
     using namespace occ;
     if (N <= 0) return 0;
     OCC_REQUIRE(xyz && knn_idxs && point_base && normals && unit_normals && (counter || att_in) && table &&
@@ -558,6 +559,8 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
     const GridLevels lv = make_grid_levels(L, S, H);
     const GridModes4 gm = modes_from_host_offsets(L, lv, h_offsets);
     FeatParams prm{bound, two_bound, nscale, (int)L};
+    OCC_REQUIRE(!rows || (nscale == 4 && !geo_idxs && !att_in && counter && h_offsets),
+                "sample_features: a row list is only supported on the renderer's path (4 scales, per-point inputs)");
     if (nscale == 4 && !geo_idxs && !att_in && counter && h_offsets) {      // the renderer's call: 8 lanes per sample
         LevelRecs levels;
         for (uint32_t l = 0; l < kMaxLevels; l++)
@@ -568,7 +571,7 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
         hipLaunchKernelGGL(sample_features8_kernel, dim3((unsigned)blocks8), dim3(256), 0, as_stream(stream), xyz,
                            N, knn_idxs, point_base, normals, unit_normals, counter,
                            reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),
-                           levels, prm, mlp_in, raw, enc_in);
+                           levels, prm, rows, mlp_in, raw, enc_in);
         return check_launch("sample_features");
     }
     int64_t blocks = (N + 255) / 256;

@@ -204,8 +204,8 @@ struct ClusteredScales {
 };
 
 __global__ __launch_bounds__(256) void msknn_clustered_kernel(
-    const float *__restrict__ xyz, int64_t n_rays, int S, const float4 *__restrict__ points,
-    const float4 *__restrict__ centers,
+    const float *__restrict__ xyz, const float *__restrict__ mask /*nullable*/, int64_t n_rays, int S,
+    const float4 *__restrict__ points, const float4 *__restrict__ centers,
     const int2 *__restrict__ ranges /*[nscale-1][ncl]*/, const float *__restrict__ radius /*[nscale-1][ncl]*/,
     ClusteredScales sc, int32_t *__restrict__ knn_idxs) {
     const int lane = threadIdx.x & 63;
@@ -227,10 +227,14 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
             const int64_t r = ray < n_rays ? ray : n_rays - 1;
             const int sm = (s0 + a) < S ? (s0 + a) : S - 1;
             qi[a] = r * S + sm;
+            // samples whose motion-weight sum is exactly 0 cannot contribute to the pixel (their alpha is
+            // multiplied by it, network.py:330): their neighbours are never read
+            if (mask && mask[qi[a]] == 0.0f) live[a] = false;
             qx[a >> 1][a & 1] = xyz[qi[a] * 3 + 0];
             qy[a >> 1][a & 1] = xyz[qi[a] * 3 + 1];
             qz[a >> 1][a & 1] = xyz[qi[a] * 3 + 2];
         }
+        if (__builtin_amdgcn_ballot_w64(live[0] || live[1] || live[2] || live[3]) == 0) continue;   // whole tile dead
         KBest64 best[kQ];
         float thr[kQ], sb[kQ];
 
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
         // coarsest scale: every point, original order
 #pragma unroll
         for (int a = 0; a < kQ; a++) {
-            thr[a] = INFINITY;
+            thr[a] = live[a] ? INFINITY : -1.0f;      // a dead query accepts no candidate (d2 >= 0)
             sb[a] = INFINITY;
             kbest64_reset(best[a]);
         }
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
 #pragma unroll
             for (int a = 0; a < kQ; a++) {
                 sb[a] = sc.seed[l] ? key_dist(best[a].k[kK - 1]) : INFINITY;
-                thr[a] = filter_bound(sb[a]);
+                thr[a] = live[a] ? filter_bound(sb[a]) : -1.0f;
                 kbest64_reset(best[a]);
             }
             const int2 *rg = ranges + (size_t)l * sc.ncl;
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
                     for (int e = 0; e < 2; e++) {
                         // reject only if surely |q-c| - r > sb  (1e-5 relative slack >> fp32 error)
                         const float lim = (sb[2 * h + e] + r) * 1.00001f;
-                        want |= !(d2[e] > lim * lim);
+                        want |= live[2 * h + e] && !(d2[e] > lim * lim);
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(want) == 0) continue;   // wave-uniform skip
@@ -434,7 +438,7 @@ OCC_API int occnerf_msknn(const float *xyz, int64_t N, const float *points,
     return check_launch("msknn");
 }
 
-OCC_API int occnerf_msknn_clustered(const float *xyz, int64_t n_rays, int32_t samples_per_ray,
+OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t n_rays, int32_t samples_per_ray,
                                     const float *points,
                                     const float *centers, const int32_t *cluster_ranges,
                                     const float *cluster_radius, int32_t ncl,
@@ -460,7 +464,7 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, int64_t n_rays, int32_t sa
     const int64_t tiles = ((n_rays + 63) / 64) * ((samples_per_ray + 3) / 4);
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > (int64_t)kNumCU * 16) blocks = (int64_t)kNumCU * 16;
-    hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz,
+    hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, mask,
                        n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points),
                        reinterpret_cast<const float4 *>(centers), reinterpret_cast<const int2 *>(cluster_ranges),
                        cluster_radius, sc, knn_idxs);

@@ -205,25 +205,52 @@ class Network(nn.Module):
         z, xyz, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale,
                                           t_rand=t_rand)
         pk = self._packed_weights()
-        if not cfg.ignore_non_rigid_motions:
+        # Samples whose motion-weight sum is exactly 0 (outside every bone's prior support or outside the
+        # canonical volume) cannot contribute: their alpha is multiplied by that sum (network.py:330).  They
+        # are dropped here -- a quarter of the samples of the benchmark frame -- and the pixel values are
+        # bit-identical to evaluating them (cfg.skip_empty_samples=False; tested).
+        N = xyz.shape[0]
+        rows = None
+        if cfg.get('skip_empty_samples', True) and cfg.get('knn_culling', True):
+            rows = torch.nonzero(mask).squeeze(1).int()          # one small device->host sync (the count)
+            if rows.numel() == N:
+                rows = None
+        if rows is not None and rows.numel() == 0:
+            raw = torch.zeros(N, 5, device=xyz.device)
+            rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
+            return rgb, acc, depth
+
+        def nonrigid(x):
             if pk['nr_bf16'] is not None:
-                xyz = ops.nonrigid_bf16x3(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'], out=xyz)
-            else:
-                xyz = ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
+                return ops.nonrigid_bf16x3(x, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'], out=x)
+            return ops.nonrigid(x, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=x)
+
+        if not cfg.ignore_non_rigid_motions:
+            if rows is None:
+                xyz = nonrigid(xyz)
+            else:                                                # offsets only for the kept samples
+                xyz[rows.long()] = nonrigid(xyz[rows.long()])
         if cfg.get('knn_culling', True):     # same results, ~5x fewer distance evaluations
-            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'])
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'],
+                                      mask=mask if rows is not None else None)
         else:
             knn = ops.msknn(xyz, ctx['points'], ctx['index_map'], ctx['scale_begin'], ctx['seed'])
-        mlp_in, raw, _ = ops.sample_features(
+        mlp_in, raw_c, _ = ops.sample_features(
             xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
-            enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution)
+            enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution,
+            rows=rows)
         del knn
         if pk['cnl_bf16'] is not None:          # opt-in split-bf16 MFMA path (cfg.mlp_precision)
-            ops.canonical_mlp_bf16x3(mlp_in, pk['cnl'], pk['cnl_bf16'], raw)
+            ops.canonical_mlp_bf16x3(mlp_in, pk['cnl'], pk['cnl_bf16'], raw_c)
         else:
-            ops.canonical_mlp(mlp_in, pk['cnl'], raw)
+            ops.canonical_mlp(mlp_in, pk['cnl'], raw_c)
         del mlp_in
+        if raw_c.shape[0] == N:
+            raw = raw_c
+        else:
+            raw = torch.zeros(N, 5, device=xyz.device)
+            raw[rows.long()] = raw_c
         rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
         return rgb, acc, depth
 

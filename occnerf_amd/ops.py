@@ -229,16 +229,17 @@ def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
     return out
 
 
-def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser):
-    """cl: device-side cluster layout (dict, see Network._context / geometry.build_knn_clusters)."""
+def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser, mask=None):
+    """cl: device-side cluster layout (dict, see Network._context / geometry.build_knn_clusters).
+    mask[n_rays*S] (optional): samples with mask == 0 are skipped, their output rows left unwritten."""
     nscale = int(cl['ranges'].shape[0]) + 1
     out = torch.empty(n_rays * S, nscale, 10, device=xyz.device, dtype=torch.int32)
     _kc, pc = _host_i32(cl['coarse_rows'])
     _ks, ps = _host_i32(seed_from_coarser)
     with _guard(xyz):
         rc = _lib.lib().occnerf_msknn_clustered(
-            _chk(xyz, torch.float32, 'xyz'), int(n_rays), int(S), _chk(cl['points'], torch.float32, 'points'),
-            _chk(cl['centers'], torch.float32, 'centers'), _chk(cl['ranges'], torch.int32, 'cluster_ranges'),
+            _chk(xyz, torch.float32, 'xyz'), _opt(mask, torch.float32, 'mask'), int(n_rays), int(S),
+            _chk(cl['points'], torch.float32, 'points'), _chk(cl['centers'], torch.float32, 'centers'), _chk(cl['ranges'], torch.int32, 'cluster_ranges'),
             _chk(cl['radius'], torch.float32, 'cluster_radius'), int(cl['ncl']), pc, ps, nscale, out.data_ptr(),
             _stream(xyz))
     _lib.check(rc, 'msknn_clustered')
@@ -298,8 +299,9 @@ def point_table(knn_base, sdf, learnable, bound32, two_bound32, embeddings, offs
 
 def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bound32, two_bound32,
                     embeddings, offsets, S, H, raw=None, want_enc_in=False, geo_idxs=None,
-                    att_in=None):
-    N = xyz.shape[0]
+                    att_in=None, rows=None):
+    """rows (int32[M], optional): compact list of samples to evaluate; outputs then have M rows."""
+    N = xyz.shape[0] if rows is None else rows.shape[0]
     dev = xyz.device
     if table.dim() != 2 or table.shape[1] != table_stride():
         raise RuntimeError(f'sample_features: table must be [P,{table_stride()}] (ops.point_table), got {tuple(table.shape)}')
@@ -315,7 +317,7 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
             float(bound32), float(two_bound32), _chk(embeddings, torch.float32, 'embeddings'),
             _chk(offsets, torch.int32, 'offsets'), _host_offsets(offsets), int(offsets.shape[0] - 1),
             float(S), int(H), _opt(geo_idxs, torch.int32, 'geo_idxs'), _opt(att_in, torch.float32, 'att_in'),
-            mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
+            _opt(rows, torch.int32, 'rows'), mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
             None if enc_in is None else enc_in.data_ptr(), _stream(xyz))
     _lib.check(rc, 'sample_features')
     return mlp_in, raw, enc_in

@@ -681,3 +681,23 @@ def test_grid_backward_tiled_vs_scatter(ops):
     scale = scat.abs().max().item()
     assert (tiled - scat).abs().max().item() <= 2e-5 * scale    # fp32 sums in different orders
     assert tiled.abs().sum().item() > 0
+
+
+def test_skip_empty_samples_is_exact(ops):
+    """Dropping the samples whose motion-weight sum is exactly 0 changes no output bit (posed free-view frame,
+    non-rigid on): rgb, alpha and depth with cfg.skip_empty_samples on and off."""
+    from occnerf_amd import synth
+    from tests.gpu_util import build_network, frame_to_device
+    net, ctx = build_network(seed=0, amplify=True, S=64, non_rigid=True)
+    frame = synth.make_frame(img_size=96, pose72=synth.seeded_pose(1), orbit_frame=28)
+    data = frame_to_device(frame, DEV)
+    outs = []
+    for skip in (True, False):
+        net.cfg.skip_empty_samples = skip
+        with torch.no_grad():
+            o = net(**data, iter_val=1e7)
+        outs.append({k: o[k].clone() for k in ('rgb', 'alpha', 'depth')})
+    net.cfg.skip_empty_samples = True
+    for k in ('rgb', 'alpha', 'depth'):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert float(outs[0]['alpha'].max()) > 0.05                 # the frame is not empty

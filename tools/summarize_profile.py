@@ -53,7 +53,8 @@ def main():
             mlp = r
     out.append('')
     if mlp is not None and line is not None:
-        n = line['config']['rays_per_frame'] * line['config']['samples_per_ray']
+        n = int(line['config'].get('samples_evaluated_per_frame',
+                                   line['config']['rays_per_frame'] * line['config']['samples_per_ray']))
         avg = float(mlp['AverageNs']) * 1e-9
         trace = sorted(glob.glob(os.path.join(args.prof_dir, '**', '*kernel_trace.csv'), recursive=True))
         if trace:                       # the timed region = the launches after the warm-up steps
@@ -74,6 +75,8 @@ def main():
         out += [f"Bench line: {line['value']:.0f} rays/s, {line['ms_per_step']:.1f} ms/frame"
                 + (f"; opt-in bf16x3 path {line['alt']['value']:.0f} rays/s, {line['alt']['ms_per_step']:.1f} ms/frame"
                    if 'alt' in line else '')
+                + (f"; every sample evaluated {line['all_samples']['value']:.0f} rays/s, {line['all_samples']['ms_per_step']:.1f} ms/frame"
+                   if 'all_samples' in line else '')
                 + (f"; CPU oracle {line['cpu_baseline']['value']:.0f} rays/s on {line['cpu_baseline']['cores']} cores"
                    if 'cpu_baseline' in line else '') + '.', '']
     open(args.prefix + '_summary.md', 'w').write('\n'.join(out))
