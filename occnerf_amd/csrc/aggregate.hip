@@ -39,19 +39,21 @@ __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restric
 // the gradient rows of kTilePoints consecutive points for the w-th slice of the samples, keeps them in LDS,
 // scans its samples (one wave per sample: the 40 ids in 40 lanes, ballot of the ones in the tile, then one
 // LDS atomic instruction per hit with lane c = column c) and finally stores the tile to partial[w] with plain
-// writes; the caller sums the W partial tables.  No global atomics.
-constexpr int kAggTileFloats = 36864;            // 144 KiB of LDS
+// writes; the caller sums the W partial tables.  No global atomics.  The LDS accumulators are fp64: ds_add_f64
+// runs at 16 cycles per wave-instruction on gfx950, ds_add_f32 at 190 (tools/lds_atomic_rate.hip) -- and the
+// sums come out more accurate for it.
+constexpr int kAggTileValues = 18432;            // doubles: 144 KiB of LDS
 
 __global__ __launch_bounds__(1024) void agg_backward_tiled_kernel(const float *__restrict__ grad_agg, int F,
                                                                   const int32_t *__restrict__ knn,
                                                                   const float *__restrict__ atts, int64_t N, int K,
                                                                   int P, int tile_points, int64_t samples_per_slice,
                                                                   float *__restrict__ partial /*[W][P][F]*/) {
-    __shared__ float s_g[kAggTileFloats];
+    __shared__ double s_g[kAggTileValues];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int tile0 = blockIdx.y * tile_points;
     const int tile_n = P - tile0 < tile_points ? P - tile0 : tile_points;
-    for (int i = threadIdx.x; i < tile_n * F; i += blockDim.x) s_g[i] = 0.0f;
+    for (int i = threadIdx.x; i < tile_n * F; i += blockDim.x) s_g[i] = 0.0;
     __syncthreads();
     const int64_t n0 = (int64_t)blockIdx.x * samples_per_slice;
     const int64_t n1 = n0 + samples_per_slice < N ? n0 + samples_per_slice : N;
@@ -68,13 +70,13 @@ __global__ __launch_bounds__(1024) void agg_backward_tiled_kernel(const float *_
                 hits &= hits - 1;
                 const int p = __builtin_amdgcn_readlane(my_id, j) - tile0;
                 const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
-                if (lane < F) atomicAdd(&s_g[p * F + lane], __fmul_rn(wj, g));
+                if (lane < F) atomicAdd(&s_g[p * F + lane], (double)__fmul_rn(wj, g));
             }
         }
     }
     __syncthreads();
     float *dst = partial + ((size_t)blockIdx.x * P + tile0) * F;
-    for (int i = threadIdx.x; i < tile_n * F; i += blockDim.x) dst[i] = s_g[i];
+    for (int i = threadIdx.x; i < tile_n * F; i += blockDim.x) dst[i] = (float)s_g[i];
 }
 
 }  // namespace occ
@@ -94,8 +96,8 @@ OCC_API int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *kn
 
 OCC_API int32_t occnerf_agg_backward_slices(int64_t N) {
     // sample slices W: with ceil(P / tile) point tiles this gives a few hundred workgroups
-    int64_t w = (N + 16383) / 16384;
-    return (int32_t)(w < 1 ? 1 : (w > 48 ? 48 : w));
+    int64_t w = (N + 32767) / 32768;
+    return (int32_t)(w < 1 ? 1 : (w > 24 ? 24 : w));
 }
 
 OCC_API int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t *knn, const float *atts, int64_t N,
@@ -105,7 +107,7 @@ OCC_API int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t
     OCC_REQUIRE(grad_agg && knn && atts && partial, "agg_backward: null argument");
     OCC_REQUIRE(F >= 1 && F <= 64 && K >= 1 && P >= 1, "agg_backward: F=%d (1..64), K=%d, P=%d", F, K, P);
     const int W = occnerf_agg_backward_slices(N);
-    const int tile_points = kAggTileFloats / F < 1024 ? kAggTileFloats / F : 1024;
+    const int tile_points = kAggTileValues / F < 1024 ? kAggTileValues / F : 1024;
     const int tiles = (P + tile_points - 1) / tile_points;
     const int64_t per_slice = (N + W - 1) / W;
     hipLaunchKernelGGL(agg_backward_tiled_kernel, dim3(W, tiles), dim3(1024), 0, as_stream(stream), grad_agg, F, knn,

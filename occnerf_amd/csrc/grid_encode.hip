@@ -191,23 +191,25 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(
 // scans ALL samples, recomputes the 16 corner indices of each (a dozen integer ops per corner) and adds the
 // contributions that fall into its tile with LDS atomics; at the end it adds the tile to the gradient table
 // with plain read-modify-writes -- no other workgroup touches those entries.  Index arithmetic is repeated
-// once per tile of the level (<= 32 times), which costs ~2 ms of integer work in total for that batch.
+// once per tile of the level (<= 64 times), which costs ~2 ms of integer work in total for that batch.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t kTileEntries = 16384;        // x 2 channels x 4 B = 128 KiB of LDS
+constexpr uint32_t kTileEntries = 8192;         // x 2 channels x 8 B (fp64 accumulators) = 128 KiB of LDS
 
 struct TileJobs {
     uint32_t n;
-    uint32_t level_tile[512];                    // level << 16 | tile
+    uint32_t level_tile[1024];                   // level << 16 | tile
     GridModes4 modes;
 };
 
 __global__ __launch_bounds__(1024) void grid_backward_tiled_d4c2_kernel(
     const float *__restrict__ grad, const float4 *__restrict__ inputs, const int32_t *__restrict__ offsets,
     float *__restrict__ grad_grid, uint32_t B, GridLevels lv, TileJobs jobs) {
-    __shared__ float s_g[kTileEntries * 2];
+    // fp64 accumulators: ds_add_f64 costs 16 cycles per wave-instruction on gfx950, ds_add_f32 190
+    // (tools/lds_atomic_rate.hip); the per-cell sums are also more accurate than the scatter kernel's
+    __shared__ double s_g[kTileEntries * 2];
     const uint32_t job = jobs.level_tile[blockIdx.x];
     const uint32_t level = job >> 16, tile = job & 0xFFFFu;
-    for (uint32_t i = threadIdx.x; i < kTileEntries * 2; i += blockDim.x) s_g[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < kTileEntries * 2; i += blockDim.x) s_g[i] = 0.0;
     __syncthreads();
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t size = (uint32_t)offsets[level + 1] - off0;
@@ -266,15 +268,15 @@ __global__ __launch_bounds__(1024) void grid_backward_tiled_d4c2_kernel(
             if (local < kTileEntries) {
                 // weight exactly as the scatter kernel forms it: ((1 * a0) * a1) * a2) * a3
                 const float w = __fmul_rn(__fmul_rn(__fmul_rn(f[0][b0], f[1][b1]), f[2][b2]), f[3][b3]);
-                atomicAdd(&s_g[local * 2], __fmul_rn(w, gv.x));
-                atomicAdd(&s_g[local * 2 + 1], __fmul_rn(w, gv.y));
+                atomicAdd(&s_g[local * 2], (double)__fmul_rn(w, gv.x));
+                atomicAdd(&s_g[local * 2 + 1], (double)__fmul_rn(w, gv.y));
             }
         }
     }
     __syncthreads();
     const uint32_t n_here = size - tile * kTileEntries < kTileEntries ? size - tile * kTileEntries : kTileEntries;
     float *dst = grad_grid + ((size_t)off0 + (size_t)tile * kTileEntries) * 2;
-    for (uint32_t i = threadIdx.x; i < n_here * 2; i += blockDim.x) dst[i] += s_g[i];
+    for (uint32_t i = threadIdx.x; i < n_here * 2; i += blockDim.x) dst[i] += (float)s_g[i];
 }
 
 // gridencoder.cu:343-369
@@ -392,7 +394,7 @@ OCC_API int occnerf_grid_encode_backward(const float *grad, const float *inputs,
             sizes[l] = (uint32_t)(h_off[l + 1] - h_off[l]);
             const uint32_t nt = (sizes[l] + kTileEntries - 1) / kTileEntries;
             for (uint32_t t = 0; t < nt; t++) {
-                if (jobs.n >= 512) { fits = false; break; }
+                if (jobs.n >= 1024) { fits = false; break; }
                 jobs.level_tile[jobs.n++] = (l << 16) | t;
             }
         }
