@@ -238,13 +238,20 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
         KBest64 best[kQ];
         float thr[kQ], sb[kQ];
 
-#define OCC_PTL(P, H)                                                                       \
+    /* one point against the lane's 4 queries: a single guard for "any of the four may enter its list" */ \
+#define OCC_PT4(P)                                                                          \
     {                                                                                       \
-        const f32x2 dx = qx[H] - P.x, dy = qy[H] - P.y, dz = qz[H] - P.z;                   \
-        const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx)); \
-        const int row = __float_as_int(P.w);                                                \
-        consider_lex(best[2 * H], thr[2 * H], sb[2 * H], d2[0], row);                       \
-        consider_lex(best[2 * H + 1], thr[2 * H + 1], sb[2 * H + 1], d2[1], row);           \
+        const f32x2 dx0 = qx[0] - P.x, dy0 = qy[0] - P.y, dz0 = qz[0] - P.z;                \
+        const f32x2 dx1 = qx[1] - P.x, dy1 = qy[1] - P.y, dz1 = qz[1] - P.z;                \
+        const f32x2 da = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0)); \
+        const f32x2 db = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1)); \
+        if ((da[0] < thr[0]) | (da[1] < thr[1]) | (db[0] < thr[2]) | (db[1] < thr[3])) {    \
+            const int row = __float_as_int(P.w);                                            \
+            consider_lex(best[0], thr[0], sb[0], da[0], row);                               \
+            consider_lex(best[1], thr[1], sb[1], da[1], row);                               \
+            consider_lex(best[2], thr[2], sb[2], db[0], row);                               \
+            consider_lex(best[3], thr[3], sb[3], db[1], row);                               \
+        }                                                                                   \
     }
     /* the next four points are fetched (scalar loads) while the current four are tested */    \
 #define OCC_SCAN(JB, JE)                                                                    \
@@ -256,8 +263,7 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
             const float4 p0 = n0, p1 = n1, p2 = n2, p3 = n3;                                \
             const int jn = j + 4 < je_ ? j + 4 : j;                                         \
             n0 = points[jn], n1 = points[jn + 1], n2 = points[jn + 2], n3 = points[jn + 3]; \
-            OCC_PTL(p0, 0) OCC_PTL(p0, 1) OCC_PTL(p1, 0) OCC_PTL(p1, 1)                     \
-            OCC_PTL(p2, 0) OCC_PTL(p2, 1) OCC_PTL(p3, 0) OCC_PTL(p3, 1)                     \
+            OCC_PT4(p0) OCC_PT4(p1) OCC_PT4(p2) OCC_PT4(p3)                                 \
         }                                                                                   \
     }
     /* .w of a point = original row << 16 | base-point index: the key's low word orders ties by row and   \
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
             }
             OCC_EMIT(l)
         }
-#undef OCC_PTL
+#undef OCC_PT4
 #undef OCC_SCAN
 #undef OCC_EMIT
     }

@@ -106,11 +106,12 @@ def bench_knn():
     grabbed = {}
     real = ops.msknn_clustered
 
-    def grab(xyz, n_rays, S, cl, seed):
-        grabbed.update(xyz=xyz.clone(), n=n_rays, S=S, cl=cl, seed=seed)
-        return real(xyz, n_rays, S, cl, seed)
+    def grab(xyz, n_rays, S, cl, seed, mask=None):
+        grabbed.update(xyz=xyz.clone(), n=n_rays, S=S, cl=cl, seed=seed, mask=mask)
+        return real(xyz, n_rays, S, cl, seed, mask=mask)
     ops.msknn_clustered = grab
-    net(**data, iter_val=1e7)
+    with torch.no_grad():
+        net(**data, iter_val=1e7)
     ops.msknn_clustered = real
     c = net._context()
     x, n, S, cl, seed = grabbed['xyz'], grabbed['n'], grabbed['S'], grabbed['cl'], grabbed['seed']
@@ -118,6 +119,9 @@ def bench_knn():
     tc = timeit(lambda: ops.msknn_clustered(x, n, S, cl, seed))
     print(f'msknn brute     : {tb:8.2f} ms')
     print(f'msknn clustered : {tc:8.2f} ms')
+    if grabbed['mask'] is not None:
+        tm = timeit(lambda: ops.msknn_clustered(x, n, S, cl, seed, mask=grabbed['mask']))
+        print(f'msknn clustered, dead samples skipped : {tm:8.2f} ms')
 
 
 def bench_stage(name):
