@@ -145,7 +145,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const floa
             const float wgt = oct == 0 ? prm.hann[0] : oct == 1 ? prm.hann[1] : oct == 2 ? prm.hann[2]
                             : oct == 3 ? prm.hann[3] : oct == 4 ? prm.hann[4] : prm.hann[5];
             const float a = __fmul_rn(pc, (float)(1 << oct));
-            const float sv = __fmul_rn(wgt, sinf(a)), cv = __fmul_rn(wgt, cosf(a));
+            float sa, ca;
+            sincosf(a, &sa, &ca);                 // one argument reduction for both
+            const float sv = __fmul_rn(wgt, sa), cv = __fmul_rn(wgt, ca);
             if (m < 4) {
                 e[T][2 * m] = sv;
                 e[T][2 * m + 1] = cv;
