@@ -10,10 +10,11 @@
 // The reference recomputes the per-point block for every 300 000-sample chunk (112x per
 // 512^2 frame); it only depends on the weights, so it is hoisted to once per frame.
 //
-// sample_features is gather-bound (L2 / Infinity Cache): algorithmic bytes per sample =
-// 16 levels x 16 corners x 8 B (hash table, 59 MiB) + 40 rows x 140 B (point table, 0.97 MB,
-// L2-resident) + 10 x (12 + 24) B neighbour positions/normals + 160 B of indices in;
-// 272 + 4 B out.  Arithmetic mirrors the oracle operation for operation (explicit
+// sample_features is gather-bound: algorithmic bytes per sample = 16 levels x 16 corners x 8 B
+// (hash table, 59 MiB) + 40 rows x 140 B (point table, 256-byte row pitch, 1.7 MB, L2-resident) +
+// 10 x (12 + 24) B neighbour positions/normals + 160 B of indices in; 272 + 4 B out.  What its time
+// actually tracks is the NUMBER of gather instructions per wave (the texture addresser spends ~16+ cycles
+// on each, whatever the active lanes or bytes): the 8-lanes-per-sample kernel is organised around that.  Arithmetic mirrors the oracle operation for operation (explicit
 // __f*_rn / __d*_rn, no contraction) so that encoder inputs are bit-identical to it.
 #include "common.h"
 
