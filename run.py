@@ -48,7 +48,8 @@ def _render(data_type, folder_name):
     model = load_network(model).eval()
     writer = ImageWriter(output_dir=os.path.join(cfg.logdir, str(cfg.load_net).replace(':', '_')),
                          exp_name=folder_name)
-    t_render, n_rays = 0.0, 0
+    t_render, n_rays, t_first, n_first = 0.0, 0, 0.0, 0
+    t_wall0 = time.perf_counter()
     for idx, batch in enumerate(loader):
         batch = {k: (v[0] if torch.is_tensor(v) or isinstance(v, list) else v) for k, v in batch.items()}
         data = {k: v.cuda() for k, v in batch.items() if k not in EXCLUDE_KEYS_TO_GPU and torch.is_tensor(v)}
@@ -68,11 +69,18 @@ def _render(data_type, folder_name):
                                                    np.array(cfg.bgcolor) / 255., out['rgb'], out['alpha'])
         imgs = [rgb_img] + ([alpha_img] if cfg.show_alpha else [])
         img_out = torch.cat(imgs, dim=1).cpu().numpy()        # uint8 over PCIe
-        t_render += time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        t_render += dt
         n_rays += int(ray_index.numel())
+        if idx == 0:                                   # includes weight packing and the per-model kNN layout
+            t_first, n_first = dt, int(ray_index.numel())
         writer.append(img_out, img_name=f'{idx:06d}' if data_type == 'movement' else None)
     writer.finalize()
     print(f'{n_rays} rays in {t_render:.3f} s -> {n_rays / max(t_render, 1e-9):.0f} rays/s (PNG writing excluded)')
+    if idx > 0:
+        print(f'first frame {t_first * 1e3:.0f} ms; frames 2..{idx + 1}: '
+              f'{(n_rays - n_first) / max(t_render - t_first, 1e-9):.0f} rays/s; wall clock with frame generation and '
+              f'PNG writing {time.perf_counter() - t_wall0:.2f} s')
 
 
 def run_tpose():
