@@ -22,6 +22,15 @@ def shard_bounds(n_rays, world_size):
     return bounds
 
 
+def shard_indices(n_rays, rank, world_size, chunk=4096):
+    """Ray indices of `rank` when rays are dealt in chunks of `chunk` consecutive rays (chunk c -> rank
+    c % world_size).  Contiguous blocks of a pixel-ordered ray list are horizontal image bands with very
+    different amounts of body in them; dealing chunks balances the work, and a chunk is still a compact
+    set of pixels for the kNN tiles.  Every rank gets the same number of rays +- one chunk."""
+    idx = torch.arange(int(n_rays))
+    return idx[(idx // int(chunk)) % int(world_size) == int(rank)]
+
+
 def shard_frame(data, rank, world_size):
     """Slice the per-ray entries of a frame dict (rays[2,R,3], near/far[R,1]) for `rank`."""
     R = data['rays'].shape[1]
@@ -49,16 +58,32 @@ def gather_rays(block, n_rays, dst=0, group=None):
     return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, bounds)], 0)
 
 
-def render_frame_sharded(net, data, iter_val=1e7, group=None):
-    """Render this rank's block of `data` and gather (rgb, alpha, depth) on rank 0.
-    Returns the full-frame dict on rank 0 and None on the other ranks."""
+def render_frame_sharded(net, data, iter_val=1e7, group=None, chunk=4096):
+    """Render this rank's share of `data` (chunks of `chunk` rays dealt round-robin, see shard_indices) and
+    gather (rgb, alpha, depth) on rank 0 -- the path's only collective.  Returns the full-frame dict in the
+    caller's ray order on rank 0 and None on the other ranks."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     R = data['rays'].shape[1]
-    local, _ = shard_frame(data, rank, world)
+    dev = data['rays'].device
+    mine = shard_indices(R, rank, world, chunk).to(dev)
+    local = dict(data)
+    local['rays'] = data['rays'][:, mine]
+    local['near'], local['far'] = data['near'][mine], data['far'][mine]
     out = net(**local, iter_val=iter_val)
     packed = torch.cat([out['rgb'], out['alpha'][:, None], out['depth'][:, None]], dim=1)
-    full = gather_rays(packed, R, dst=0, group=group)
-    if full is None:
-        return None
+    if world == 1:
+        full = packed
+    else:
+        sizes = [int(shard_indices(R, r, world, chunk).numel()) for r in range(world)]
+        width = max(sizes)
+        padded = packed.new_zeros((width, packed.shape[1]))
+        padded[:packed.shape[0]] = packed
+        bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+        dist.gather(padded, bufs, dst=0, group=group)
+        if rank != 0:
+            return None
+        full = packed.new_empty((R, packed.shape[1]))
+        for r in range(world):
+            full[shard_indices(R, r, world, chunk).to(dev)] = bufs[r][:sizes[r]]
     return {'rgb': full[:, :3], 'alpha': full[:, 3], 'depth': full[:, 4]}

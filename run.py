@@ -4,7 +4,12 @@
 
 Frames go to experiments/<category>/<task>/<subject>/<experiment>/<load_net>/<folder>/NNNNNN.png
 exactly like the reference (run.py:79-81, image_util.py:53-75).  `load_net: seeded[:N]` renders the
-seeded random-init checkpoint (occnerf_amd/checkpoint.py) when no .tar is on disk."""
+seeded random-init checkpoint (occnerf_amd/checkpoint.py) when no .tar is on disk.
+
+Several GPUs: start it under torchrun, one process per GPU --
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 run.py --cfg ... --type movement
+every rank renders its share of each frame's rays (occnerf_amd/parallel.py) and rank 0 gathers them over
+RCCL, assembles and writes the images."""
 import os
 import time
 
@@ -17,6 +22,7 @@ cfg.bgcolor = [255., 255., 255.]
 from core.data import create_dataloader  # noqa: E402
 from core.nets import create_network  # noqa: E402
 from occnerf_amd.image import ImageWriter, assemble_uint8_device  # noqa: E402
+from occnerf_amd.parallel import render_frame_sharded  # noqa: E402
 from occnerf_amd.rays import frame_rays  # noqa: E402
 
 EXCLUDE_KEYS_TO_GPU = ['frame_name', 'img_width', 'img_height', 'ray_mask',
@@ -40,14 +46,27 @@ def load_network(model):
     return model.cuda().deploy_mlps_to_secondary_gpus()
 
 
+def _init_ranks():
+    """One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE); a plain launch is world 1."""
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    if world > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group('nccl', rank=rank, world_size=world,
+                                             device_id=torch.device('cuda', torch.cuda.current_device()))
+    return rank, world
+
+
 def _render(data_type, folder_name):
     cfg.perturb = 0.
+    rank, world = _init_ranks()
     model = create_network()
     loader = create_dataloader(data_type)
     model.generate_neural_points(loader.dataset.avg_betas)
     model = load_network(model).eval()
     writer = ImageWriter(output_dir=os.path.join(cfg.logdir, str(cfg.load_net).replace(':', '_')),
-                         exp_name=folder_name)
+                         exp_name=folder_name) if rank == 0 else None
     t_render, n_rays, t_first, n_first = 0.0, 0, 0.0, 0
     t_wall0 = time.perf_counter()
     for idx, batch in enumerate(loader):
@@ -64,7 +83,10 @@ def _render(data_type, folder_name):
         else:
             ray_index = torch.nonzero(batch['ray_mask'].cuda()).squeeze(1)
         with torch.no_grad():
-            out = model(**data, iter_val=cfg.eval_iter)
+            out = render_frame_sharded(model, data, iter_val=cfg.eval_iter) if world > 1 else \
+                model(**data, iter_val=cfg.eval_iter)
+        if out is None:                               # ranks > 0: their rays went to rank 0
+            continue
         rgb_img, alpha_img = assemble_uint8_device(int(batch['img_width']), int(batch['img_height']), ray_index,
                                                    np.array(cfg.bgcolor) / 255., out['rgb'], out['alpha'])
         imgs = [rgb_img] + ([alpha_img] if cfg.show_alpha else [])
@@ -75,12 +97,19 @@ def _render(data_type, folder_name):
         if idx == 0:                                   # includes weight packing and the per-model kNN layout
             t_first, n_first = dt, int(ray_index.numel())
         writer.append(img_out, img_name=f'{idx:06d}' if data_type == 'movement' else None)
+    if world > 1:
+        torch.distributed.barrier()
+        if rank != 0:
+            torch.distributed.destroy_process_group()
+            return
     writer.finalize()
     print(f'{n_rays} rays in {t_render:.3f} s -> {n_rays / max(t_render, 1e-9):.0f} rays/s (PNG writing excluded)')
     if idx > 0:
         print(f'first frame {t_first * 1e3:.0f} ms; frames 2..{idx + 1}: '
               f'{(n_rays - n_first) / max(t_render - t_first, 1e-9):.0f} rays/s; wall clock with frame generation and '
               f'PNG writing {time.perf_counter() - t_wall0:.2f} s')
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def run_tpose():

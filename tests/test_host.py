@@ -75,6 +75,16 @@ def test_shard_bounds():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_shard_indices_partition():
+    from occnerf_amd.parallel import shard_indices
+    for n, w, c in [(183784, 8, 4096), (1001, 2, 64), (7, 8, 4), (0, 2, 16), (5000, 3, 4096)]:
+        parts = [shard_indices(n, r, w, c) for r in range(w)]
+        allidx = torch.cat(parts).sort().values
+        assert torch.equal(allidx, torch.arange(n))
+        sizes = [p.numel() for p in parts]
+        assert max(sizes) - min(sizes) <= c
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -96,7 +106,7 @@ def _gloo_worker(rank, world, port, n_rays, q):
     g = torch.Generator().manual_seed(0)
     data = {'rays': torch.rand(2, n_rays, 3, generator=g), 'near': torch.rand(n_rays, 1, generator=g),
             'far': torch.rand(n_rays, 1, generator=g)}
-    out = render_frame_sharded(FakeNet(), data)
+    out = render_frame_sharded(FakeNet(), data, chunk=96)
     if rank == 0:
         ok = (torch.equal(out['rgb'], data['rays'][0] * 2.0) and torch.equal(out['alpha'], data['near'][:, 0] + 1.0)
               and torch.equal(out['depth'], data['far'][:, 0] * 3.0))
