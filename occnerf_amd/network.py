@@ -212,9 +212,8 @@ class Network(nn.Module):
         N = xyz.shape[0]
         rows = None
         if cfg.get('skip_empty_samples', True) and cfg.get('knn_culling', True):
-            rows = torch.nonzero(mask).squeeze(1).int()          # one small device->host sync (the count)
-            if rows.numel() == N:
-                rows = None
+            rows64 = torch.nonzero(mask).squeeze(1)              # one small device->host sync (the count)
+            rows = None if rows64.numel() == N else rows64.int()
         if rows is not None and rows.numel() == 0:
             raw = torch.zeros(N, 5, device=xyz.device)
             rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
@@ -229,7 +228,7 @@ class Network(nn.Module):
             if rows is None:
                 xyz = nonrigid(xyz)
             else:                                                # offsets only for the kept samples
-                xyz[rows.long()] = nonrigid(xyz[rows.long()])
+                xyz[rows64] = nonrigid(xyz[rows64])
         if cfg.get('knn_culling', True):     # same results, ~5x fewer distance evaluations
             knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'],
                                       mask=mask if rows is not None else None)
@@ -250,7 +249,7 @@ class Network(nn.Module):
             raw = raw_c
         else:
             raw = torch.zeros(N, 5, device=xyz.device)
-            raw[rows.long()] = raw_c
+            raw[rows64] = raw_c
         rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
         return rgb, acc, depth
 
