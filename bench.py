@@ -18,6 +18,10 @@ with HIP events recorded on the launch stream around every launch inside the tim
 `cpu_baseline`: the CPU oracle (a port of the reference path, OpenMP on all host cores of
 this box) on a bounded ray sample of the same frame -- only the checker being timed, never
 part of the product path.
+`all_samples`: the same frame with cfg.skip_empty_samples off.  By default the renderer does not
+evaluate the samples whose motion-weight sum is exactly 0 (their alpha is multiplied by it, so the
+pixels are bit-identical; a quarter of this frame's samples); `roofline` counts FLOPs only for the
+samples a launch processes.  `alt`: the opt-in split-bf16 MLP path.
 """
 import argparse
 import json
@@ -199,7 +203,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: free-view frame, 512x512 image, 128 samples/ray, '
                                    'non-rigid motion on, seeded random-init checkpoint; synthetic SMPL-like body '
-                                   f'and camera; {R} rays hit the body bbox (ray_mask), one frame per GPU per step',
+                                   f'and camera; {R} rays hit the body bbox (ray_mask), one frame per GPU per step; samples whose '
+                                   'motion-weight sum is exactly 0 are dropped after the warp (bit-identical pixels, see all_samples)',
                        'rays_per_frame': R, 'samples_per_ray': SPP, 'image': [IMG, IMG],
                        'samples_evaluated_per_frame': float(np.mean(nsmp)),
                        'skip_empty_samples': bool(net.cfg.get('skip_empty_samples', True)),
