@@ -109,13 +109,14 @@ def main():
     # HIP events around every launch of the dominant kernel, on the stream it is launched on
     mlp_events, real_mlp = [], ops.canonical_mlp
 
-    def timed_mlp(mlp_in, packed, raw):
+    def timed_mlp(mlp_in, packed, raw, count=None, **kw):
         s = torch.cuda.current_stream(mlp_in.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
-        out = real_mlp(mlp_in, packed, raw)
+        out = real_mlp(mlp_in, packed, raw, count=count, **kw)
         e1.record(s)
-        mlp_events.append((e0, e1, mlp_in.shape[0]))
+        # rows the launch really processes: the device-side live count when the renderer passes one
+        mlp_events.append((e0, e1, mlp_in.shape[0] if count is None else count.clone()))
         return out
     ops.canonical_mlp = timed_mlp
 
@@ -193,7 +194,7 @@ def main():
 
     if rank == 0:
         ms = [e0.elapsed_time(e1) for e0, e1, _ in mlp_events]
-        nsmp = [n for _, _, n in mlp_events]
+        nsmp = [int(n) for _, _, n in mlp_events]          # (read back after the timed region)
         avg_ms = float(np.mean(ms))
         achieved = FLOP_PER_SAMPLE_CNL * float(np.mean(nsmp)) / (avg_ms * 1e-3)
         line = {

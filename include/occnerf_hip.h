@@ -111,6 +111,11 @@ int occnerf_nonrigid_pack(const float *const *h_W, const float *const *h_b, floa
 int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
                      const float *W0, const float *b0, float *packed, float *xyz_out,
                      void *stream);
+/* occnerf_nonrigid, in place, on the samples rows[0 .. *n_dev) of xyz[N_max,3] only (the frame's live samples;
+ * list and count in device memory, occnerf_live_rows). */
+int occnerf_nonrigid_rows(float *xyz, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
+                          const float *cond, const float *h_hann, const float *W0, const float *b0,
+                          float *packed, void *stream);
 /* The first fp32 version (32-sample waves, weights straight from L2); same arguments and packed buffer,
  * same results to fp32 rounding.  Cross-check and A/B timing; occnerf_nonrigid is the LDS-staged
  * 16-sample-tile kernel. */
@@ -202,7 +207,8 @@ int occnerf_point_table(const double *knn_base, const float *point_sdf, const fl
  * counts already gathered, used instead of counter[knn_idxs]); NULL for the normal path.
  * rows (nullable, renderer's path only): a compact list of N sample indices into xyz / knn_idxs -- the
  * samples that can contribute to their pixel (motion-weight sum != 0); output row m then belongs to
- * sample rows[m]. */
+ * sample rows[m].  n_dev (nullable, needs rows): the length of the list in device memory; N is then the
+ * capacity of the outputs. */
 int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs, int32_t nscale,
                             const float *point_base, const double *normals,
                             const double *unit_normals, const float *counter,
@@ -210,7 +216,7 @@ int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs
                             const float *embeddings, const int32_t *offsets,
                             const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
                             const int32_t *geo_idxs, const float *att_in, const int32_t *rows,
-                            float *mlp_in, float *raw, float *enc_in, void *stream);
+                            const int32_t *n_dev, float *mlp_in, float *raw, float *enc_in, void *stream);
 
 /* Differentiable neighbour aggregation of the training path (occnerf_mlp.py:86-126 simple_agg with the
  * gather of :176-178): agg[n,:] = sum_j atts[n,j] * feats[knn[n,j],:] for feats[P,F] (F <= 64), knn[N,K],
@@ -223,6 +229,16 @@ int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *knn, const
 int32_t occnerf_agg_backward_slices(int64_t N);
 int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t *knn, const float *atts, int64_t N,
                          int32_t K, int32_t P, float *partial, void *stream);
+
+/* Live samples of a frame (mask = per-sample motion-weight sum, network.py:330: alpha is multiplied by it).
+ * rows[0 .. *count) = ascending indices of the samples with mask != 0, both in device memory; temp = device
+ * scratch of occnerf_live_rows_temp_bytes(N) bytes.  occnerf_scatter_raw copies the compact raw_c[m, 0..4] rows
+ * to raw_full[rows[m], 0..4] for m < *n_dev (raw_full zero-initialised by the caller). */
+int64_t occnerf_live_rows_temp_bytes(int64_t N);
+int occnerf_live_rows(const float *mask, int64_t N, int32_t *rows, int32_t *count, void *temp,
+                      int64_t temp_bytes, void *stream);
+int occnerf_scatter_raw(const float *raw_c, const int32_t *rows, const int32_t *n_dev, int64_t N_max,
+                        float *raw_full, void *stream);
 
 /* Canonical MLP weights -> MFMA operand order.  h_W/h_b: HOST arrays of the 10 device
  * weight/bias pointers in module order: pts_linears.{0,2,4,6}, geo_linear.0,
@@ -243,6 +259,10 @@ int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *packed, f
                           void *stream);
 int occnerf_canonical_mlp_direct(const float *mlp_in, int64_t N, const float *packed, float *raw,
                                  void *stream);
+/* occnerf_canonical_mlp with the row count in DEVICE memory (n_dev, written by occnerf_live_rows on the same
+ * stream): the launch covers N_max rows and the workgroups beyond *n_dev leave at once. */
+int occnerf_canonical_mlp_counted(const float *mlp_in, int64_t N_max, const int32_t *n_dev,
+                                  const float *packed, float *raw, void *stream);
 
 /* The same two trunks on the bf16 matrix pipe with split operands ("bf16x3"): every fp32
  * weight and activation is carried as hi + lo bf16 (16 significand bits) and each product is

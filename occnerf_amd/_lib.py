@@ -39,11 +39,16 @@ SIGNATURES = {
     'occnerf_agg_forward': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     'occnerf_agg_backward_slices': (_i32, [_i64]),
     'occnerf_agg_backward': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    'occnerf_live_rows_temp_bytes': (_i64, [_i64]),
+    'occnerf_live_rows': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    'occnerf_scatter_raw': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    'occnerf_canonical_mlp_counted': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    'occnerf_nonrigid_rows': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_point_table_stride': (_i32, []),
     'occnerf_point_table': (C.c_int, [_vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _u32, _f32, _u32, _vp,
                                        _vp]),
     'occnerf_sample_features': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp,
-                                           _vp, _vp, _u32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                           _vp, _vp, _u32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp_packed_floats': (_i64, []),
     'occnerf_canonical_mlp_pack': (C.c_int, [_vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),

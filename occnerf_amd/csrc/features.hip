@@ -314,14 +314,16 @@ __device__ __forceinline__ float grp_max8(float v) {
 }
 
 __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
-    const float *__restrict__ xyz, int64_t N, const int32_t *__restrict__ knn_idxs,
+    const float *__restrict__ xyz, int64_t N_max, const int32_t *__restrict__ knn_idxs,
     const float *__restrict__ point_base, const double *__restrict__ normals,
     const double *__restrict__ unit, const float *__restrict__ counter,
     const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
     LevelRecs levels, FeatParams prm, const int32_t *__restrict__ rows /*nullable: compact list of samples*/,
-    float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
+    const int32_t *__restrict__ n_dev /*nullable: device-side count of rows*/, float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
     constexpr int NK = 4 * kKnn;                       // 40 neighbours over 4 scales
     const int g = threadIdx.x & 7;
+    const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
+    if (N <= 0) return;
     const int64_t group0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> 3;
     const int64_t iters = (N + ngroups - 1) / ngroups;
@@ -548,8 +550,8 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                                     const float *embeddings, const int32_t *offsets,
                                     const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
                                     const int32_t *geo_idxs,
-                                    const float *att_in, const int32_t *rows, float *mlp_in, float *raw,
-                                    float *enc_in, void *stream) {
+                                    const float *att_in, const int32_t *rows, const int32_t *n_dev,
+                                    float *mlp_in, float *raw, float *enc_in, void *stream) {
     using namespace occ;
     if (N <= 0) return 0;
     OCC_REQUIRE(xyz && knn_idxs && point_base && normals && unit_normals && (counter || att_in) && table &&
@@ -560,6 +562,7 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
     const GridLevels lv = make_grid_levels(L, S, H);
     const GridModes4 gm = modes_from_host_offsets(L, lv, h_offsets);
     FeatParams prm{bound, two_bound, nscale, (int)L};
+    OCC_REQUIRE(!n_dev || rows, "sample_features: a device-side count needs the row list");
     OCC_REQUIRE(!rows || (nscale == 4 && !geo_idxs && !att_in && counter && h_offsets),
                 "sample_features: a row list is only supported on the renderer's path (4 scales, per-point inputs)");
     if (nscale == 4 && !geo_idxs && !att_in && counter && h_offsets) {      // the renderer's call: 8 lanes per sample
@@ -572,7 +575,7 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
         hipLaunchKernelGGL(sample_features8_kernel, dim3((unsigned)blocks8), dim3(256), 0, as_stream(stream), xyz,
                            N, knn_idxs, point_base, normals, unit_normals, counter,
                            reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),
-                           levels, prm, rows, mlp_in, raw, enc_in);
+                           levels, prm, rows, n_dev, mlp_in, raw, enc_in);
         return check_launch("sample_features");
     }
     int64_t blocks = (N + 255) / 256;

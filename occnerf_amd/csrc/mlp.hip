@@ -797,7 +797,15 @@ OCC_API int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *p
     using namespace occ;
     if (N <= 0) return 0;
     OCC_REQUIRE(mlp_in && packed && raw, "canonical_mlp: null argument");
-    return mlp_lds_launch(mlp_in, N, packed + Blob::kTotal, raw, as_stream(stream));
+    return mlp_lds_launch(mlp_in, N, nullptr, packed + Blob::kTotal, raw, as_stream(stream));
+}
+
+OCC_API int occnerf_canonical_mlp_counted(const float *mlp_in, int64_t N_max, const int32_t *n_dev,
+                                          const float *packed, float *raw, void *stream) {
+    using namespace occ;
+    if (N_max <= 0) return 0;
+    OCC_REQUIRE(mlp_in && n_dev && packed && raw, "canonical_mlp_counted: null argument");
+    return mlp_lds_launch(mlp_in, N_max, n_dev, packed + Blob::kTotal, raw, as_stream(stream));
 }
 
 OCC_API int occnerf_canonical_mlp_direct(const float *mlp_in, int64_t N, const float *packed, float *raw,

@@ -165,9 +165,15 @@ __device__ __forceinline__ float dot_row(const f32x4 (&act)[kOB], const float *W
 
 static_assert(kFrags == 4, "OCC16_ENTER waits with vmcnt(8) = 2 chunks x 4 DMAs per wave");
 
+// n_dev (nullable): the number of rows actually present, in device memory (the live-sample count of the
+// frame, written by occnerf_live_rows on the same stream); the launch is sized for N_max rows and the
+// workgroups beyond *n_dev leave at once -- no host round trip to learn the count.
 __global__ __launch_bounds__(kWaves * 64, 2) void canonical_mlp_lds_kernel(const float *__restrict__ mlp_in,
-                                                                           int64_t N, const float *__restrict__ pk,
+                                                                           int64_t N_max, const int32_t *__restrict__ n_dev,
+                                                                           const float *__restrict__ pk,
                                                                            float *__restrict__ raw) {
+    const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
+    if ((int64_t)blockIdx.x * (16 * kWaves) >= N) return;          // uniform for the workgroup
     // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read)
     __shared__ __attribute__((aligned(16))) f32x4 smem[kRingSlots * kChunkF4 + Aux::kTotal / 4];
     f32x4 *ring = smem;
@@ -368,12 +374,13 @@ int mlp_lds_pack(const float *const *h_W, const float *const *h_b, float *packed
     return check_launch("canonical_mlp_pack");
 }
 
-int mlp_lds_launch(const float *mlp_in, int64_t N, const float *packed, float *raw, hipStream_t st) {
+int mlp_lds_launch(const float *mlp_in, int64_t N, const int32_t *n_dev, const float *packed, float *raw,
+                   hipStream_t st) {
     const int64_t per_block = 16 * m16::kWaves;
     const int64_t blocks = (N + per_block - 1) / per_block;
     OCC_REQUIRE(blocks < (1LL << 31), "canonical_mlp: N too large for one launch");
     hipLaunchKernelGGL(m16::canonical_mlp_lds_kernel, dim3((unsigned)blocks), dim3(64 * m16::kWaves), 0, st, mlp_in, N,
-                       packed, raw);
+                       n_dev, packed, raw);
     return check_launch("canonical_mlp");
 }
 

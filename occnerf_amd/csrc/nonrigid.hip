@@ -522,7 +522,18 @@ OCC_API int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, 
     using namespace occ;
     if (N <= 0) return 0;
     OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && xyz_out, "nonrigid: null argument");
-    return nr_lds_launch(xyz_in, N, cond, h_hann, W0, b0, packed + NrBlob::kTotal, xyz_out, as_stream(stream));
+    return nr_lds_launch(xyz_in, N, nullptr, nullptr, cond, h_hann, W0, b0, packed + NrBlob::kTotal, xyz_out,
+                         as_stream(stream));
+}
+
+OCC_API int occnerf_nonrigid_rows(float *xyz, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
+                                  const float *cond, const float *h_hann, const float *W0, const float *b0,
+                                  float *packed, void *stream) {
+    using namespace occ;
+    if (N_max <= 0) return 0;
+    OCC_REQUIRE(xyz && rows && n_dev && cond && h_hann && W0 && b0 && packed, "nonrigid_rows: null argument");
+    return nr_lds_launch(xyz, N_max, rows, n_dev, cond, h_hann, W0, b0, packed + NrBlob::kTotal, xyz,
+                         as_stream(stream));
 }
 
 OCC_API int occnerf_nonrigid_direct(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,

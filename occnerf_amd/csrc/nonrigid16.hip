@@ -114,9 +114,15 @@ struct Params {
 
 #define NR16_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-__global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const float *__restrict__ xyz_in, int64_t N,
+// rows / n_dev (both nullable): evaluate only the samples rows[0 .. *n_dev) of xyz (the frame's live samples,
+// occnerf_live_rows); the launch is sized for N_max and workgroups beyond the device-side count leave at once.
+__global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const float *__restrict__ xyz_in, int64_t N_max,
+                                                                      const int32_t *__restrict__ rows,
+                                                                      const int32_t *__restrict__ n_dev,
                                                                       const float *__restrict__ pk, Params prm,
                                                                       float *__restrict__ xyz_out) {
+    const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
+    if ((int64_t)blockIdx.x * (32 * kWaves) >= N) return;          // uniform for the workgroup
     // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read)
     __shared__ __attribute__((aligned(16))) f32x4 smem[kRingSlots * kChunkF4 + Aux::kTotal / 4];
     f32x4 *ring = smem;
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const floa
 #pragma unroll
     for (int T = 0; T < 2; T++) {
         const int64_t n = base + T * 16 + s;
-        const int64_t nsrc = n < N ? n : N - 1;      // the whole workgroup stays alive for the barriers
+        const int64_t nm = n < N ? n : N - 1;        // the whole workgroup stays alive for the barriers
+        const int64_t nsrc = rows ? (int64_t)rows[nm] : nm;
 #pragma unroll
         for (int c = 0; c < 3; c++) p[T][c] = xyz_in[nsrc * 3 + c];
 #pragma unroll
@@ -271,8 +278,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const floa
         }
         const int64_t n = base + T * 16 + s;
         if (g == 0 && n < N) {
+            const int64_t nd = rows ? (int64_t)rows[n] : n;
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) xyz_out[n * 3 + ch] = __fadd_rn(p[T][ch], off[ch]);
+            for (int ch = 0; ch < 3; ch++) xyz_out[nd * 3 + ch] = __fadd_rn(p[T][ch], off[ch]);
         }
     }
 #undef BOP_E
@@ -310,8 +318,9 @@ int nr_lds_pack(const float *const *h_W, const float *const *h_b, float *packed,
     return check_launch("nonrigid_pack");
 }
 
-int nr_lds_launch(const float *xyz_in, int64_t N, const float *cond, const float *h_hann, const float *W0,
-                  const float *b0, float *packed, float *xyz_out, hipStream_t st) {
+int nr_lds_launch(const float *xyz_in, int64_t N, const int32_t *rows, const int32_t *n_dev, const float *cond,
+                  const float *h_hann, const float *W0, const float *b0, float *packed, float *xyz_out,
+                  hipStream_t st) {
     using namespace nr16;
     hipLaunchKernelGGL(nr16::fold_bias_kernel, dim3(1), dim3(128), 0, st, W0, b0, cond,
                        packed + Stream::kAux + Aux::kL0B);
@@ -320,8 +329,8 @@ int nr_lds_launch(const float *xyz_in, int64_t N, const float *cond, const float
     const int64_t per_block = 32 * kWaves;
     const int64_t blocks = (N + per_block - 1) / per_block;
     OCC_REQUIRE(blocks < (1ll << 31), "nonrigid: N too large");
-    hipLaunchKernelGGL(nr16::nonrigid_lds_kernel, dim3((unsigned)blocks), dim3(64 * kWaves), 0, st, xyz_in, N, packed,
-                       prm, xyz_out);
+    hipLaunchKernelGGL(nr16::nonrigid_lds_kernel, dim3((unsigned)blocks), dim3(64 * kWaves), 0, st, xyz_in, N, rows,
+                       n_dev, packed, prm, xyz_out);
     return check_launch("nonrigid");
 }
 

@@ -210,9 +210,30 @@ class Network(nn.Module):
         # are dropped here -- a quarter of the samples of the benchmark frame -- and the pixel values are
         # bit-identical to evaluating them (cfg.skip_empty_samples=False; tested).
         N = xyz.shape[0]
+        fp32 = pk['cnl_bf16'] is None and pk['nr_bf16'] is None
+        if cfg.get('skip_empty_samples', True) and cfg.get('knn_culling', True) and fp32:
+            # list and count of the live samples stay on the device: no host round trip in the frame
+            rows, count = ops.live_rows(mask)
+            self.last_live_count = count
+            if not cfg.ignore_non_rigid_motions:
+                ops.nonrigid_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=mask)
+            mlp_in, raw_c, _ = ops.sample_features(
+                xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
+                self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
+                enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution,
+                rows=rows, count=count)
+            del knn
+            ops.canonical_mlp(mlp_in, pk['cnl'], raw_c, count=count)
+            del mlp_in
+            raw = ops.scatter_raw(raw_c, rows, count, torch.zeros(N, 5, device=xyz.device))
+            rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
+            return rgb, acc, depth
+
+        # split-bf16 kernels (opt-in) take the list through the host: one nonzero = one sync
         rows = None
         if cfg.get('skip_empty_samples', True) and cfg.get('knn_culling', True):
-            rows64 = torch.nonzero(mask).squeeze(1)              # one small device->host sync (the count)
+            rows64 = torch.nonzero(mask).squeeze(1)
             rows = None if rows64.numel() == N else rows64.int()
         if rows is not None and rows.numel() == 0:
             raw = torch.zeros(N, 5, device=xyz.device)

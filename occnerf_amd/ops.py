@@ -192,6 +192,45 @@ def nonrigid(xyz, cond, hann, W0, b0, packed, out=None, direct=False):
     return out
 
 
+def nonrigid_rows(xyz, rows, count, cond, hann, W0, b0, packed):
+    """Non-rigid offsets, in place, for the samples rows[0 .. count) only (list and count on the device)."""
+    _kh, ph = _host_f32(hann, 6)
+    with _guard(xyz):
+        rc = _lib.lib().occnerf_nonrigid_rows(
+            _chk(xyz, torch.float32, 'xyz'), rows.shape[0], _chk(rows, torch.int32, 'rows'),
+            _chk(count, torch.int32, 'count'), _chk(cond, torch.float32, 'cond'), ph,
+            _chk(W0, torch.float32, 'W0'), _chk(b0, torch.float32, 'b0'), _chk(packed, torch.float32, 'packed'),
+            _stream(xyz))
+    _lib.check(rc, 'nonrigid_rows')
+    return xyz
+
+
+def live_rows(mask):
+    """-> rows int32[N] (first count entries valid: ascending indices with mask != 0), count int32[1]; no sync."""
+    N = mask.shape[0]
+    dev = mask.device
+    nbytes = int(_lib.lib().occnerf_live_rows_temp_bytes(N))
+    if nbytes < 0:
+        raise RuntimeError('live_rows: temp size query failed')
+    temp = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
+    rows = torch.empty(N, device=dev, dtype=torch.int32)
+    count = torch.empty(1, device=dev, dtype=torch.int32)
+    with _guard(mask):
+        rc = _lib.lib().occnerf_live_rows(_chk(mask, torch.float32, 'mask'), N, rows.data_ptr(), count.data_ptr(),
+                                          temp.data_ptr(), nbytes, _stream(mask))
+    _lib.check(rc, 'live_rows')
+    return rows, count
+
+
+def scatter_raw(raw_c, rows, count, raw_full):
+    with _guard(raw_c):
+        rc = _lib.lib().occnerf_scatter_raw(_chk(raw_c, torch.float32, 'raw_c'), _chk(rows, torch.int32, 'rows'),
+                                            _chk(count, torch.int32, 'count'), rows.shape[0],
+                                            _chk(raw_full, torch.float32, 'raw_full'), _stream(raw_c))
+    _lib.check(rc, 'scatter_raw')
+    return raw_full
+
+
 def nonrigid_pack_bf16(weights):
     dev = weights[0].device
     n = _lib.lib().occnerf_nonrigid_packed_bf16_bytes()
@@ -299,8 +338,9 @@ def point_table(knn_base, sdf, learnable, bound32, two_bound32, embeddings, offs
 
 def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bound32, two_bound32,
                     embeddings, offsets, S, H, raw=None, want_enc_in=False, geo_idxs=None,
-                    att_in=None, rows=None):
-    """rows (int32[M], optional): compact list of samples to evaluate; outputs then have M rows."""
+                    att_in=None, rows=None, count=None):
+    """rows (int32[M], optional): compact list of samples to evaluate; outputs then have M rows.
+    count (int32[1] on the device, optional, with rows): the list's real length; M is then a capacity."""
     N = xyz.shape[0] if rows is None else rows.shape[0]
     dev = xyz.device
     if table.dim() != 2 or table.shape[1] != table_stride():
@@ -317,7 +357,7 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
             float(bound32), float(two_bound32), _chk(embeddings, torch.float32, 'embeddings'),
             _chk(offsets, torch.int32, 'offsets'), _host_offsets(offsets), int(offsets.shape[0] - 1),
             float(S), int(H), _opt(geo_idxs, torch.int32, 'geo_idxs'), _opt(att_in, torch.float32, 'att_in'),
-            _opt(rows, torch.int32, 'rows'), mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
+            _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'), mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
             None if enc_in is None else enc_in.data_ptr(), _stream(xyz))
     _lib.check(rc, 'sample_features')
     return mlp_in, raw, enc_in
@@ -335,8 +375,16 @@ def canonical_mlp_pack(weights, biases):
     return packed
 
 
-def canonical_mlp(mlp_in, packed, raw, direct=False):
-    """fp32 MLP trunks.  direct=True: the 32-sample-wave direct-load kernel (cross-check / A-B timing)."""
+def canonical_mlp(mlp_in, packed, raw, direct=False, count=None):
+    """fp32 MLP trunks.  direct=True: the 32-sample-wave direct-load kernel (cross-check / A-B timing).
+    count (int32[1] on the device): only the first count rows exist; the host does not know the number."""
+    if count is not None:
+        with _guard(mlp_in):
+            rc = _lib.lib().occnerf_canonical_mlp_counted(
+                _chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0], _chk(count, torch.int32, 'count'),
+                _chk(packed, torch.float32, 'packed'), _chk(raw, torch.float32, 'raw'), _stream(mlp_in))
+        _lib.check(rc, 'canonical_mlp_counted')
+        return raw
     fn = _lib.lib().occnerf_canonical_mlp_direct if direct else _lib.lib().occnerf_canonical_mlp
     with _guard(mlp_in):
         rc = fn(_chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0], _chk(packed, torch.float32, 'packed'),

@@ -701,3 +701,23 @@ def test_skip_empty_samples_is_exact(ops):
     for k in ('rgb', 'alpha', 'depth'):
         assert torch.equal(outs[0][k], outs[1][k]), k
     assert float(outs[0]['alpha'].max()) > 0.05                 # the frame is not empty
+
+
+@pytest.mark.parametrize('n', [1, 255, 70001])
+def test_live_rows_and_scatter(ops, n):
+    """Device-side live-sample list (no host sync) against torch.nonzero; scatter of compact raw rows."""
+    g = torch.Generator(device='cpu').manual_seed(n)
+    mask = torch.rand(n, generator=g)
+    mask[torch.rand(n, generator=g) < 0.4] = 0.0
+    if n == 255:
+        mask[:] = 0.0                                               # nothing alive
+    md = mask.to(DEV)
+    rows, count = ops.live_rows(md)
+    want = torch.nonzero(md).squeeze(1).int()
+    m = int(count)
+    assert m == want.numel() and torch.equal(rows[:m], want)
+    raw_c = torch.arange(n * 5, device=DEV, dtype=torch.float32).reshape(n, 5)
+    full = ops.scatter_raw(raw_c, rows, count, torch.zeros(n, 5, device=DEV))
+    ref = torch.zeros(n, 5, device=DEV)
+    ref[want.long()] = raw_c[:m]
+    assert torch.equal(full, ref)
