@@ -60,6 +60,16 @@ int occnerf_grid_encode_backward(const float *grad, const float *inputs, const f
                                  const float *dy_dx, float *grad_inputs, uint32_t gridtype,
                                  int align_corners, uint32_t interp, void *stream);
 
+/* occnerf_grid_encode_backward with the level offsets also given as a HOST array h_offsets[L+1].  The
+ * reference's signature above cannot know the level sizes without reading device memory, so it always runs
+ * the atomic scatter (gridencoder.cu:248-340 as written); with the host copy, large D = 4, C = 2 hash batches
+ * take the atomics-free path (workgroup-owned LDS tiles of the table, fp64 accumulators). */
+int occnerf_grid_encode_backward_h(const float *grad, const float *inputs, const float *embeddings,
+                                   const int32_t *offsets, const int32_t *h_offsets, float *grad_embeddings,
+                                   uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                   const float *dy_dx, float *grad_inputs, uint32_t gridtype, int align_corners,
+                                   uint32_t interp, void *stream);
+
 /* Total-variation gradient, gridencoder.cu:506-645.  Never called by the reference's
  * trainer; exported for interface completeness and
  * returns an error ("not implemented") without touching its arguments. */
@@ -286,6 +296,64 @@ int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const float *pa
 int occnerf_composite(const float *raw, const float *mask, const float *z_vals, const float *rays,
                       const float *h_bgcolor, int64_t n, int32_t S, float *rgb, float *acc,
                       float *depth, float *weights, int32_t *term, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * 3. Training step (BASELINE configs[4]).  The reference
+ *    trains through torch autograd over nn.Linear / F.grid_sample / cumprod (trainer.py:239-249,
+ *    occnerf_mlp.py:183-199, network.py:320-402); these are the hand-written forward-with-saved-
+ *    activations and backward kernels the autograd Functions of occnerf_amd/train_ops.py call.
+ * ---------------------------------------------------------------------------------- */
+
+/* Linear layers on the matrix pipe, element type bf16 (bf16 != 0: v_mfma_f32_32x32x16_bf16, fp32
+ * accumulate) or fp32 (v_mfma_f32_32x32x2_f32, exact).  All matrices are row-major with widths padded to
+ * multiples of 32 elements (zero padding is exact: padded weights and activations are zeros).
+ *
+ * occnerf_linear_pack: W[out_dim,in_dim] fp32 (torch layout), b[out_dim] or NULL ->
+ *   Wp[n_pad,k_pad] with Wp[n][k] = W[row_map[n]][col_map[k]] (0 where a map entry is -1), Wt[k_pad,n_pad] its
+ *   transpose (either may be NULL), bias_p[n_pad] fp32 (may be NULL).  row_map/col_map: int32 device arrays.
+ * occnerf_linear_forward: y[m,n] = epi(sum_k x[m,k] W[n,k]), x = [x0 | x1] two column segments (k1 = 0: one),
+ *   ld* row pitches in ELEMENTS; epi = (+bias[n]) (ReLU) (zero where mask[m,n] <= 0), each optional;
+ *   stored as the element type, or fp32 when out_f32; only columns < n_store are stored;
+ *   aux (optional): column aux_col is also written, in fp32, to aux[m * aux_stride].
+ *   Forward of a layer: W = Wp, bias, relu.  Input gradient of a layer: x = dZ, W = Wt, mask = the layer's
+ *   saved input (its ReLU mask).
+ * occnerf_linear_wgrad: part[G,n_pad,k_pad] / dbpart[G,n_pad] = per-workgroup partial sums over row slices of
+ *   dZ^T X and of the column sums of dZ, G = occnerf_linear_wgrad_slices(M); occnerf_linear_wgrad_reduce adds
+ *   the G slices into dW[out_dim,in_dim] (and db) through the same row/col maps (accumulate != 0: += ). */
+int occnerf_linear_pack(const float *W, const float *b, int32_t out_dim, int32_t in_dim, const int32_t *row_map,
+                        int32_t n_pad, const int32_t *col_map, int32_t k_pad, int32_t bf16, void *Wp, void *Wt,
+                        float *bias_p, void *stream);
+int occnerf_linear_forward(const void *x0, int64_t ld0, int32_t k0, const void *x1, int64_t ld1, int32_t k1,
+                           const void *W, const float *bias, int32_t relu, const void *mask, int64_t ldm, void *y,
+                           int64_t ldy, int32_t out_f32, int32_t n_store, float *aux, int32_t aux_col,
+                           int64_t aux_stride, int64_t M, int32_t n_pad, int32_t bf16, void *stream);
+int32_t occnerf_linear_wgrad_slices(int64_t M);
+int occnerf_linear_wgrad(const void *dz, int64_t lddz, int32_t n_pad, const void *x, int64_t ldx, int32_t k_pad,
+                         int64_t M, int32_t bf16, float *part, float *dbpart, void *stream);
+int occnerf_linear_wgrad_reduce(const float *part, const float *dbpart, int32_t G, int32_t n_pad, int32_t k_pad,
+                                const int32_t *row_map, const int32_t *col_map, float *dW, int32_t in_dim, float *db,
+                                int32_t accumulate, void *stream);
+
+/* Backward of occnerf_composite (network.py:320-348 under autograd): g_rgb[n,3], g_acc[n], g_depth[n] (each may
+ * be NULL = zero) -> d_raw[n*S,5] (column 4 = 0) and d_mask[n*S] (optional).  S <= 256. */
+int occnerf_composite_backward(const float *raw, const float *mask, const float *z_vals, const float *rays,
+                               const float *h_bgcolor, int64_t n, int32_t S, const float *g_rgb, const float *g_acc,
+                               const float *g_depth, float *d_raw, float *d_mask, void *stream);
+
+/* Backward of occnerf_sample_warp's mask output (network.py:351-402 under autograd; x_skel carries no gradient in
+ * the reference's graph: it only enters CanonicalMLP through no_grad quantities).  g_mask[n*S] ->
+ * d_vol_part[W,nb,G,G,G] and d_rt_part[W,nb,12] (rows: dRs[3,3] then dTs[3]) with
+ * W = occnerf_warp_backward_slices(n*S); the caller sums over W.  G must be 32. */
+int32_t occnerf_warp_backward_slices(int64_t n_samples);
+int occnerf_warp_backward(const float *rays, int64_t n, int32_t S, const float *z_vals, const float *g_mask,
+                          const float *Rs, const float *Ts, const float *vol, int32_t nb, int32_t G,
+                          const float *h_bbox_min, const float *h_bbox_scale, float *d_vol_part, float *d_rt_part,
+                          void *stream);
+
+/* Attention weights of simple_agg (occnerf_mlp.py:110-125): counter[P], knn[N,K] (K <= 40) -> atts[N,K]
+ * (softmax) and var[N] (unbiased variance of the normalised counts). */
+int occnerf_agg_weights(const float *counter, const int32_t *knn, int64_t N, int32_t K, float *atts, float *var,
+                        void *stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,8 @@ SIGNATURES = {
                                                _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grid_encode_backward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
                                                 _u32, _vp, _vp, _u32, C.c_int, _u32, _vp]),
+    'occnerf_grid_encode_backward_h': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
+                                                  _u32, _vp, _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grad_total_variation': (C.c_int, [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32,
                                                 _u32, _u32, C.c_int, _vp]),
     'occnerf_sample_warp': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
@@ -57,6 +59,16 @@ SIGNATURES = {
     'occnerf_canonical_mlp_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_canonical_mlp_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     'occnerf_composite': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_linear_pack': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'occnerf_linear_forward': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32,
+                                          _i32, _vp, _i32, _i64, _i64, _i32, _i32, _vp]),
+    'occnerf_linear_wgrad_slices': (_i32, [_i64]),
+    'occnerf_linear_wgrad': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp]),
+    'occnerf_linear_wgrad_reduce': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
+    'occnerf_composite_backward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_warp_backward_slices': (_i32, [_i64]),
+    'occnerf_warp_backward': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_agg_weights': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -357,35 +357,21 @@ OCC_API int occnerf_grid_encode_forward(const float *inputs, const float *embedd
     }
 }
 
-OCC_API int occnerf_grid_encode_backward(const float *grad, const float *inputs,
-                                         const float *embeddings, const int32_t *offsets,
-                                         float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
-                                         uint32_t L, float S, uint32_t H, const float *dy_dx,
-                                         float *grad_inputs, uint32_t gridtype, int align_corners,
-                                         uint32_t interp, void *stream) {
+static int grid_backward_impl(const float *grad, const float *inputs, const int32_t *offsets, const int32_t *h_off,
+                              float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                              uint32_t H, const float *dy_dx, float *grad_inputs, uint32_t gridtype,
+                              int align_corners, uint32_t interp, void *stream) {
     using namespace occ;
-    (void)embeddings;
     if (B == 0) return 0;
     OCC_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null tensor");
     OCC_REQUIRE((dy_dx == nullptr) == (grad_inputs == nullptr),
                 "grid_encode_backward: dy_dx and grad_inputs must be given together");
     OCC_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L=%u unsupported", L);
-    if (B == 0) return 0;
     const GridLevels lv = make_grid_levels(L, S, H);
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
-    if (D == 4 && C == 2 && gridtype == 0 && !ac && interp == 0 && B >= 32768) {
-        // tiled, atomics-free path; needs the level sizes on the host (cached per offsets pointer)
-        static const int32_t *cached_ptr = nullptr;
-        static uint32_t cached_L = 0;
-        static int32_t h_off[kMaxLevels + 1];
-        if (cached_ptr != offsets || cached_L != L) {
-            OCC_REQUIRE(hipMemcpyAsync(h_off, offsets, sizeof(int32_t) * (L + 1), hipMemcpyDeviceToHost, st) == hipSuccess &&
-                            hipStreamSynchronize(st) == hipSuccess,
-                        "grid_encode_backward: reading the level offsets failed");
-            cached_ptr = offsets;
-            cached_L = L;
-        }
+    if (h_off && D == 4 && C == 2 && gridtype == 0 && !ac && interp == 0 && B >= 32768) {
+        // tiled, atomics-free path; the level sizes come from the caller's HOST copy of the offsets
         TileJobs jobs;
         jobs.n = 0;
         uint32_t sizes[kMaxLevels] = {0};
@@ -415,6 +401,27 @@ OCC_API int occnerf_grid_encode_backward(const float *grad, const float *inputs,
         case 5: return launch_backward_c<5>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, st);
         default: set_error("GridEncoding: D must be 2, 3, 4, or 5."); return 1;
     }
+}
+
+OCC_API int occnerf_grid_encode_backward(const float *grad, const float *inputs, const float *embeddings,
+                                         const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
+                                         uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
+                                         float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
+                                         void *stream) {
+    (void)embeddings;
+    return grid_backward_impl(grad, inputs, offsets, nullptr, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
+                              gridtype, align_corners, interp, stream);
+}
+
+OCC_API int occnerf_grid_encode_backward_h(const float *grad, const float *inputs, const float *embeddings,
+                                           const int32_t *offsets, const int32_t *h_offsets, float *grad_embeddings,
+                                           uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                           const float *dy_dx, float *grad_inputs, uint32_t gridtype,
+                                           int align_corners, uint32_t interp, void *stream) {
+    (void)embeddings;
+    OCC_REQUIRE(h_offsets, "grid_encode_backward_h: null host offsets");
+    return grid_backward_impl(grad, inputs, offsets, h_offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
+                              gridtype, align_corners, interp, stream);
 }
 
 OCC_API int occnerf_grad_total_variation(const float *, const float *, float *, const int32_t *,

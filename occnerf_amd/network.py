@@ -166,19 +166,23 @@ class Network(nn.Module):
         return self._ctx
 
     def _packed_weights(self):
-        if self._packed is not None and not self.training:
-            return self._packed
+        """MFMA-ordered MLP weights, repacked whenever a packed parameter changed (optimizer steps update
+        the tensors in place: their `_version` counters move, whatever mode the module is in)."""
         cm, nr = self.cnl_mlp.module, self.non_rigid_mlp.module
         nr_lin = [m for m in nr.block_mlps if isinstance(m, nn.Linear)]
         cw, cb = cm.linear_params()
+        bf16x3 = self.cfg.get('mlp_precision', 'fp32') == 'bf16x3'
+        srcs = cw + cb + [m.weight for m in nr_lin] + [m.bias for m in nr_lin]
+        key = (bf16x3,) + tuple((t.data_ptr(), t._version) for t in srcs)
+        if self._packed is not None and self._packed['key'] == key:
+            return self._packed
         self._packed = {
+            'key': key,
             'cnl': ops.canonical_mlp_pack(cw, cb),
-            'cnl_bf16': ops.canonical_mlp_pack_bf16(cw) if self.cfg.get('mlp_precision', 'fp32') == 'bf16x3'
-            else None,
+            'cnl_bf16': ops.canonical_mlp_pack_bf16(cw) if bf16x3 else None,
             'nr': ops.nonrigid_pack([m.weight.detach() for m in nr_lin],
                                     [m.bias.detach() for m in nr_lin]),
-            'nr_bf16': ops.nonrigid_pack_bf16([m.weight.detach() for m in nr_lin])
-            if self.cfg.get('mlp_precision', 'fp32') == 'bf16x3' else None,
+            'nr_bf16': ops.nonrigid_pack_bf16([m.weight.detach() for m in nr_lin]) if bf16x3 else None,
             'nr_w0': nr_lin[0].weight.detach(), 'nr_b0': nr_lin[0].bias.detach(),
         }
         return self._packed
@@ -303,9 +307,9 @@ class Network(nn.Module):
 
     @staticmethod
     def _host3(v):
-        if torch.is_tensor(v):
-            v = v.detach().cpu().numpy()
-        return np.asarray(v, dtype=np.float32).reshape(3)
+        """Per-frame float[3] constants (bbox min / scale, background colour) as host float32: the kernels take
+        them by value (ops.host_float3: no copy for host arrays, one per tensor object for device tensors)."""
+        return ops.host_float3(v)
 
     def forward(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None,
                 near=None, far=None, iter_val=1e7, **kwargs):
@@ -317,7 +321,17 @@ class Network(nn.Module):
         dst_Rs, dst_Ts = dst_Rs[None], dst_Ts[None]
         dst_posevec, cnl_gtfms = dst_posevec[None], cnl_gtfms[None]
         motion_weights_priors = motion_weights_priors[None]
-        want_grad = torch.is_grad_enabled()      # autograd path (training) vs fused HIP path (render)
+        want_grad = torch.is_grad_enabled()
+        # fused HIP render when no graph is wanted and the module is in eval mode; the staged differentiable
+        # path otherwise (training mode under no_grad still produces comp_loss and the counter update, as the
+        # reference's `if self.training` branch does, network.py:486)
+        fused = not want_grad and not self.training
+        R = int(near.numel())
+        shape = list(rays[1].shape[:-1])
+        if R == 0:                                   # a rank's empty shard / a frame that misses the bbox
+            z = torch.zeros(0, device=dev)
+            return {'rgb': z.reshape(shape + [3]), 'alpha': z.reshape(shape), 'depth': z.reshape(shape),
+                    'comp_loss': torch.zeros(0 if self.training else 1, device=dev)}
 
         with torch.set_grad_enabled(want_grad):
             # ---- per frame, torch (network.py:557-596) ----
@@ -339,24 +353,21 @@ class Network(nn.Module):
             order = self._ray_patch_order(rays8[:, 3:6]) if cfg.get('ray_patch_order', True) else None
             rays8 = (rays8[order] if order is not None else rays8).contiguous()
             S = int(cfg.N_samples)
+            bbox_min = self._host3(kwargs['cnl_bbox_min_xyz'])
+            bbox_scale = self._host3(kwargs['cnl_bbox_scale_xyz'])
+            bgcolor = self._host3(kwargs['bgcolor'])
             outs = []
-            if want_grad:
-                # ---- differentiable path: torch autograd over HIP kNN + HIP grid encoder ----
+            if not fused:
+                # ---- differentiable path: HIP forward + HIP backward per stage (train_path.py) ----
                 from . import train_path
-                bmin = torch.as_tensor(self._host3(kwargs['cnl_bbox_min_xyz']), device=dev)
-                bscale = torch.as_tensor(self._host3(kwargs['cnl_bbox_scale_xyz']), device=dev)
-                bg = torch.as_tensor(self._host3(kwargs['bgcolor']), device=dev)
                 t_rand = kwargs.get('t_rand')            # optional injected jitter [R,S] (tests)
                 if t_rand is not None and order is not None:
                     t_rand = t_rand[order]
                 for i in range(0, rays8.shape[0], int(cfg.chunk)):
                     outs.append(train_path.render_rays_autograd(
-                        self, rays8[i:i + cfg.chunk], Rs[0], Ts[0], vol, bmin, bscale, bg, cond.float(),
-                        hann.to(dev), None if t_rand is None else t_rand[i:i + cfg.chunk]))
+                        self, rays8[i:i + cfg.chunk], Rs[0], Ts[0], vol, bbox_min, bbox_scale, bgcolor, cond.float(),
+                        hann.tolist(), None if t_rand is None else t_rand[i:i + cfg.chunk]))
             else:
-                bbox_min = self._host3(kwargs['cnl_bbox_min_xyz'])
-                bbox_scale = self._host3(kwargs['cnl_bbox_scale_xyz'])
-                bgcolor = self._host3(kwargs['bgcolor'])
                 table = self._point_stage(self._context())
                 # ---- per sample, HIP; all rays of the frame in as few passes as memory allows ----
                 rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 26)) // S)
@@ -374,7 +385,6 @@ class Network(nn.Module):
                 rgb, acc, depth = rgb[inv], acc[inv], depth[inv]
                 if comp_loss.shape[0] == order.numel():
                     comp_loss = comp_loss[inv]
-        shape = list(rays_d.shape[:-1])
         return {'rgb': rgb.reshape(shape + [3]), 'alpha': acc.reshape(shape),
                 'depth': depth.reshape(shape),
                 'comp_loss': comp_loss.reshape(-1)}

@@ -58,20 +58,45 @@ def _host_i32(vals):
     return a, a.ctypes.data_as(C.c_void_p)
 
 
-_host_offsets_cache = {}
+class _HostCopies:
+    """Host copies of small constant device tensors (level offsets, per-frame float[3] constants), fetched with
+    one blocking copy the first time a tensor OBJECT is seen.  Keyed by object identity (checked through a weak
+    reference) and version counter -- never by device address, which the caching allocator recycles."""
+
+    def __init__(self, limit=256):
+        self._items, self._limit = {}, limit
+
+    def get(self, t, convert):
+        import weakref
+        hit = self._items.get(id(t))
+        if hit is not None and hit[0]() is t and hit[1] == t._version:
+            return hit[2]
+        if len(self._items) > self._limit:
+            self._items = {k: v for k, v in self._items.items() if v[0]() is not None}
+            if len(self._items) > self._limit:
+                self._items.clear()
+        val = convert(t)
+        self._items[id(t)] = (weakref.ref(t), t._version, val)
+        return val
+
+
+_host_copies = _HostCopies()
 
 
 def _host_offsets(offsets):
-    """Host copy of a (constant) level-offset tensor, fetched once per tensor."""
-    key = (offsets.data_ptr(), offsets.shape[0], offsets._version)
-    hit = _host_offsets_cache.get(key)
-    if hit is None:
-        a = np.ascontiguousarray(offsets.detach().cpu().numpy().astype(np.int32))
-        hit = (a, a.ctypes.data_as(C.c_void_p))
-        if len(_host_offsets_cache) > 64:
-            _host_offsets_cache.clear()
-        _host_offsets_cache[key] = hit
-    return hit[1]
+    """Host copy of a (constant) level-offset tensor, fetched once per tensor object."""
+    def convert(t):
+        a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.int32))
+        return a, a.ctypes.data_as(C.c_void_p)
+    return _host_copies.get(offsets, convert)[1]
+
+
+def host_float3(v):
+    """float[3] per-frame constant (bbox min / scale, background colour) as host float32: free for host arrays,
+    one blocking copy per tensor object for device tensors."""
+    if torch.is_tensor(v):
+        return _host_copies.get(v, lambda t: np.asarray(t.detach().cpu().numpy(), dtype=np.float32).reshape(3).copy())
+    return np.asarray(v, dtype=np.float32).reshape(3)
 
 
 def _ptr_table(tensors, name):
@@ -98,11 +123,11 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
                          dy_dx=None, grad_inputs=None, gridtype=0, align_corners=False, interp=0):
     """`_gridencoder.grid_encode_backward` (bindings.cpp:7)."""
     with _guard(inputs):
-        rc = _lib.lib().occnerf_grid_encode_backward(
+        rc = _lib.lib().occnerf_grid_encode_backward_h(
             _chk(grad, torch.float32, 'grad'), _chk(inputs, torch.float32, 'inputs'),
             _chk(embeddings, torch.float32, 'embeddings'), _chk(offsets, torch.int32, 'offsets'),
-            _chk(grad_embeddings, torch.float32, 'grad_embeddings'), int(B), int(D), int(Cc), int(L),
-            float(S), int(H), _opt(dy_dx, torch.float32, 'dy_dx'),
+            _host_offsets(offsets), _chk(grad_embeddings, torch.float32, 'grad_embeddings'), int(B), int(D), int(Cc),
+            int(L), float(S), int(H), _opt(dy_dx, torch.float32, 'dy_dx'),
             _opt(grad_inputs, torch.float32, 'grad_inputs'), int(gridtype),
             int(bool(align_corners)), int(interp), _stream(inputs))
     _lib.check(rc, 'grid_encode_backward')

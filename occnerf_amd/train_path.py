@@ -1,26 +1,30 @@
-"""Differentiable evaluation of the sample path (SURVEY.md section 8 rows a18, a19; config 5).
+"""Differentiable evaluation of the sample path (SURVEY.md section 8 rows a18, a19, f1; config 5).
 
-Rendering (no grad) goes through the fused HIP kernels.  When gradients are needed the same
-chain is evaluated here so that torch autograd can differentiate it:
+Rendering (no grad) goes through the fused HIP kernels of Network._render_rays.  When gradients are needed the
+same chain is evaluated here, stage by stage, each stage a HIP forward that keeps what its HIP backward needs
+(occnerf_amd/train_ops.py, include/occnerf_hip.h section 3):
 
-  * the pieces whose results are integers or constants stay HIP: the multi-scale kNN
-    (`ops.msknn_clustered`), the per-point k=3 / visibility k=10 searches (`ops.knn_small`);
-  * the hash-grid encoder is the HIP operator behind an autograd Function
-    (occnerf_amd/gridencoder.py: forward + `grid_encode_backward` with fp32 atomics, and the
-    dy_dx input gradient for the per-point call whose inputs depend on `point_dist`);
-  * the rest (warp via F.grid_sample, MLPs via nn.Linear, aggregation, compositing) is plain
-    torch on the GPU, written to mirror the reference's graph including its `detach()` /
-    `no_grad` cuts: network.py:351-402, 263-284, 320-348, 486-519; occnerf_mlp.py:86-199.
-    Dedicated backward kernels for these are the next step.
+  sampler + warp      ops.sample_warp forward; backward of `mask` w.r.t. the motion-weight volume and the motion
+                      bases (network.py:351-402, 405-432, 456)
+  non-rigid MLP       HIP forward only: in the reference's graph `xyz` enters CanonicalMLP through no_grad
+                      quantities alone (occnerf_mlp.py:144-167), so this MLP receives no gradient from the
+                      rendering loss (the reference's own gradients for it are None; tests/golden/train_*)
+  kNN, geometry       HIP (integers / no_grad quantities): ops.msknn_clustered, ops.sample_features
+  hash encoding       HIP operator forward/backward behind occnerf_amd/gridencoder.py
+  aggregation         HIP forward/backward (ops.aggregate), weights by train_ops.agg_weights
+  MLP trunks          train_ops.canonical_trunks: ten MFMA layers forward, wgrad + dgrad backward (bf16 or fp32)
+  compositing         train_ops.composite forward/backward (network.py:320-348)
+  a18                 comp_loss and the point_counter update: a few elementwise torch ops on [n,S] (network.py:486-519)
 
-One consequence of the reference's cuts worth knowing: `xyz` only enters CanonicalMLP through
-`no_grad` quantities, so the non-rigid MLP receives no gradient from the rendering loss.
+The per-point block (network.py:263-284, P = 6 890 rows, gradient to point_dist) stays torch.
+`render_rays_autograd_torch` is the first, all-torch-autograd evaluation of the same chain (nn.Linear,
+F.grid_sample, cumprod); it is kept as the fp32 reference the HIP stages are tested against.
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, train_ops
 
 
 def sample_along_rays(rays8, S, perturb, t_rand=None):
@@ -133,8 +137,9 @@ def raw2outputs(raw, mask, z_vals, rays_d, bgcolor):
     return rgb_map, acc, depth, term
 
 
-def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, t_rand=None):
-    """Differentiable counterpart of Network._render_rays (+ the training branch a18)."""
+def render_rays_autograd_torch(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, t_rand=None):
+    """All-torch-autograd evaluation (nn.Linear, F.grid_sample, cumprod) of the chain below: the fp32 reference the
+    HIP stages are tested against.  bbox_min, bbox_scale, bgcolor: device tensors."""
     cfg, ctx = net.cfg, net._context()
     S = int(cfg.N_samples)
     n = rays8.shape[0]
@@ -164,4 +169,91 @@ def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor,
             net.point_counter.data[kidx.view(-1).long()] += 1.                   # duplicates count once
     else:
         comp_loss = torch.zeros(1, 1, device=rays8.device)
+    return rgb, acc, depth, comp_loss
+
+
+def _training_branch(net, raw, depth, term, cnl_pts):
+    """network.py:486-517: comp_loss per sample and the visibility-counter update (training mode only)."""
+    dist, sigma = raw[..., 4:], raw[..., 3:4]        # (a slice: the reference's list index [3] backpropagates as an index_put)
+    comp_loss = (dist < 0.).float().detach() * torch.exp(torch.clamp(-F.relu(sigma), min=-10, max=0))
+    comp_loss = comp_loss.squeeze(-1) * 10.
+    depth_mask = depth.detach() > 0.5
+    if int(depth_mask.sum()) > 1:
+        tp = term[depth_mask].detach().long()
+        term_pts = torch.gather(cnl_pts[depth_mask].detach(), 1, tp[:, :, None].expand(-1, 1, 3)).squeeze(1)
+        kidx = ops.knn_small(term_pts.float().contiguous(), net.point_cloud.detach().float().contiguous(), 10)
+        net.point_counter.data[kidx.view(-1).long()] += 1.                       # duplicates count once
+    return comp_loss
+
+
+def _use_bf16(cfg):
+    """bf16 trunks when the caller runs under torch.autocast(bfloat16) (train.py, `train.bf16`) or asks for it
+    with cfg.train_precision = 'bf16'; exact fp32 otherwise."""
+    want = str(cfg.get('train_precision', 'auto'))
+    if want == 'auto':
+        return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+    if want not in ('bf16', 'fp32'):
+        raise RuntimeError(f"cfg.train_precision must be 'auto', 'bf16' or 'fp32', got {want!r}")
+    return want == 'bf16'
+
+
+def canonical_mlp_hip(cm, xyz, knn_idxs, net, knn_base, point_sdf, ctx, bf16):
+    """occnerf_mlp.py:142-199 -> raw[N,5]; every per-sample stage a HIP forward + HIP backward."""
+    enc = cm.encoder
+    N = knn_idxs.shape[0]
+    pc = net.point_cloud.float()
+    with torch.no_grad():
+        # geometry prelude (:144-167, all no_grad in the reference): encoder input [q, normed] and the signed distance
+        table = ops.point_table(knn_base.detach().double().contiguous(), point_sdf.detach().reshape(-1).float().contiguous(),
+                                pc.detach().contiguous(), ctx['bound32'], ctx['two_bound32'], enc.embeddings.detach(),
+                                enc.offsets, enc.log2_per_level_scale, enc.base_resolution)
+        _, raw_d, enc_in = ops.sample_features(
+            xyz.detach().contiguous(), knn_idxs, net.point_base.detach(), ctx['normals'], ctx['unit'],
+            net.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'], enc.embeddings.detach(), enc.offsets,
+            enc.log2_per_level_scale, enc.base_resolution, want_enc_in=True)
+        dist = raw_d[:, 4:5]
+        knn40 = knn_idxs.reshape(N, -1)
+        atts, var = train_ops.agg_weights(net.point_counter.detach().float().contiguous(), knn40)
+    with torch.autocast('cuda', enabled=False):
+        h = enc(enc_in, bound=None)                                                  # [N,32], gradient to the table
+        bound = cm.bound
+        pc01 = (knn_base + bound) / (2 * bound)
+        sdf01 = torch.clamp((point_sdf + 0.2) / 0.8, 0.0, 1.0)
+        feats = enc(torch.cat((pc01, sdf01), dim=-1).float(), bound=None)
+        feats = torch.cat((feats, pc), dim=-1)                                       # [P,35]
+        agg = ops.aggregate(feats, knn40, atts)
+        raw4 = train_ops.canonical_trunks(cm, agg, var, h, bf16)
+    return torch.cat((raw4, dist), dim=-1)
+
+
+def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, t_rand=None):
+    """Differentiable counterpart of Network._render_rays (+ the training branch a18).
+    bbox_min, bbox_scale, bgcolor: HOST float32[3]; hann: HOST list of the 6 window weights."""
+    cfg, ctx = net.cfg, net._context()
+    S = int(cfg.N_samples)
+    n = rays8.shape[0]
+    dev = rays8.device
+    t_vals = torch.linspace(0., 1., steps=S, device=dev)
+    if float(cfg.perturb) > 0.:
+        t_rand = (torch.rand(n, S, device=dev) if t_rand is None else t_rand).float().contiguous()
+    else:
+        t_rand = None
+    with torch.autocast('cuda', enabled=False):
+        z, cnl, mask = train_ops.sample_warp(rays8, S, t_vals, t_rand, Rs.float(), Ts.float(), vol.float(), bbox_min,
+                                             bbox_scale)
+    xyz = cnl
+    if not cfg.ignore_non_rigid_motions:
+        pk = net._packed_weights()
+        with torch.no_grad():
+            xyz = ops.nonrigid(cnl, cond.reshape(-1).float().contiguous(), hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
+    with torch.no_grad():
+        knn = ops.msknn_clustered(xyz, n, S, ctx['clusters'], ctx['seed'])
+    with torch.autocast('cuda', enabled=False):
+        knn_base, sdf = point_sdf_block(net)
+        raw = canonical_mlp_hip(net.cnl_mlp.module, xyz, knn, net, knn_base, sdf, ctx, _use_bf16(cfg))
+        rgb, acc, depth, term = train_ops.composite(raw, mask, z, rays8, bgcolor)
+        if net.training:
+            comp_loss = _training_branch(net, raw.reshape(n, S, 5), depth, term.reshape(n, 1), cnl.reshape(n, S, 3))
+        else:
+            comp_loss = torch.zeros(1, 1, device=dev)
     return rgb, acc, depth, comp_loss

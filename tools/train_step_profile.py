@@ -7,6 +7,8 @@ from tests.gpu_util import build_network, frame_to_device
 from occnerf_amd import synth
 net, ctx = build_network(0, False, S=128, non_rigid=True)
 net.cfg.perturb = 1.0
+net.cfg.train_precision = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+print('train_precision', net.cfg.train_precision)
 net.train()
 frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
 R = frame['rays'].shape[1]
@@ -31,4 +33,4 @@ torch.cuda.synchronize(); print('train step ms', (time.perf_counter() - t0) / 3 
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=60))
+print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=70, max_name_column_width=60))
