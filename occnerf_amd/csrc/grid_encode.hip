@@ -252,25 +252,48 @@ __global__ __launch_bounds__(1024) void grid_backward_tiled_d4c2_kernel(
             }
         }
         const float2 gv = g2[b];
+        if (gv.x == 0.0f && gv.y == 0.0f) continue;          // adds exact zeros (e.g. samples the compositor masks out)
+        if (mode == kGridGeneric) {
+#pragma unroll
+            for (uint32_t idx = 0; idx < 16; idx++) {
+                const int b0 = idx & 1, b1 = (idx >> 1) & 1, b2 = (idx >> 2) & 1, b3 = (idx >> 3) & 1;
+                const uint32_t pl[4] = {pg[0] + b0, pg[1] + b1, pg[2] + b2, pg[3] + b3};
+                const uint32_t local = grid_index<4>(0, false, size, resolution, pl) - tile * kTileEntries;
+                if (local < kTileEntries) {
+                    const float w = __fmul_rn(__fmul_rn(__fmul_rn(f[0][b0], f[1][b1]), f[2][b2]), f[3][b3]);
+                    atomicAdd(&s_g[local * 2], (double)__fmul_rn(w, gv.x));
+                    atomicAdd(&s_g[local * 2 + 1], (double)__fmul_rn(w, gv.y));
+                }
+            }
+            continue;
+        }
+        // Which of the 16 corners fall into this tile (1 in 64 on a hashed level).  An LDS atomic costs its
+        // ~16 cycles per wave-instruction however few lanes are active, and with one conditional pair per corner
+        // almost every one of the 32 instructions finds SOME lane with a hit: the LDS port was the bound of this
+        // kernel.  So the hits are first collected as a per-lane bit mask and then drained together: the wave
+        // issues max-over-lanes(hits) pairs (2-3) instead of 32.
+        const bool dense = mode == kGridDense;
+        uint32_t hits = 0;
 #pragma unroll
         for (uint32_t idx = 0; idx < 16; idx++) {
             const int b0 = idx & 1, b1 = (idx >> 1) & 1, b2 = (idx >> 2) & 1, b3 = (idx >> 3) & 1;
-            uint32_t index;
-            if (mode == kGridDense) {
-                index = t[0][b0] + t[1][b1] + t[2][b2] + t[3][b3];
-            } else if (mode == kGridHashPow2) {
-                index = (t[0][b0] ^ t[1][b1] ^ t[2][b2] ^ t[3][b3]) & (size - 1);
-            } else {
-                const uint32_t pl[4] = {pg[0] + b0, pg[1] + b1, pg[2] + b2, pg[3] + b3};
-                index = grid_index<4>(0, false, size, resolution, pl);
-            }
+            const uint32_t index = dense ? t[0][b0] + t[1][b1] + t[2][b2] + t[3][b3]
+                                         : (t[0][b0] ^ t[1][b1] ^ t[2][b2] ^ t[3][b3]) & (size - 1);
+            if (index - tile * kTileEntries < kTileEntries) hits |= 1u << idx;
+        }
+        while (hits) {
+            const uint32_t c = (uint32_t)__builtin_ctz(hits);
+            hits &= hits - 1;
+            const uint32_t t0 = (c & 1) ? t[0][1] : t[0][0], t1 = (c & 2) ? t[1][1] : t[1][0];
+            const uint32_t t2 = (c & 4) ? t[2][1] : t[2][0], t3 = (c & 8) ? t[3][1] : t[3][0];
+            const uint32_t index = dense ? t0 + t1 + t2 + t3 : (t0 ^ t1 ^ t2 ^ t3) & (size - 1);
             const uint32_t local = index - tile * kTileEntries;
-            if (local < kTileEntries) {
-                // weight exactly as the scatter kernel forms it: ((1 * a0) * a1) * a2) * a3
-                const float w = __fmul_rn(__fmul_rn(__fmul_rn(f[0][b0], f[1][b1]), f[2][b2]), f[3][b3]);
-                atomicAdd(&s_g[local * 2], (double)__fmul_rn(w, gv.x));
-                atomicAdd(&s_g[local * 2 + 1], (double)__fmul_rn(w, gv.y));
-            }
+            // weight exactly as the scatter kernel forms it: ((1 * a0) * a1) * a2) * a3
+            const float w = __fmul_rn(__fmul_rn(__fmul_rn((c & 1) ? f[0][1] : f[0][0], (c & 2) ? f[1][1] : f[1][0]),
+                                                (c & 4) ? f[2][1] : f[2][0]),
+                                      (c & 8) ? f[3][1] : f[3][0]);
+            atomicAdd(&s_g[local * 2], (double)__fmul_rn(w, gv.x));
+            atomicAdd(&s_g[local * 2 + 1], (double)__fmul_rn(w, gv.y));
         }
     }
     __syncthreads();

@@ -22,9 +22,10 @@
 // linear_kernel.  A workgroup of 4 waves owns 128 rows and ALL (<= 256) output columns; the product is formed
 // transposed, D'[n][m] = sum_k W[n][k] X[m][k] (A operand = 32 weight rows, B operand = 32 sample rows), so
 // that a lane ends up with 4 consecutive output columns of one row and stores them as one 8/16-byte piece.
-// K runs in chunks of 256 bytes per row: the weight chunk [N][256 B] is staged in LDS (row pitch 272 B: the
-// 16-lane groups of ds_read_b128 then cover all 64 banks), the sample fragments come straight from global
-// memory (32 rows x 32 contiguous bytes per load instruction).  A second K segment lets a layer read its input
+// K runs in chunks of 256 bytes per row: the weight chunk [N][256 B] is brought into LDS by LDS-DMA (16-byte
+// pieces XOR-swizzled by row so that the 16-lane groups of ds_read_b128 cover all 64 banks), the sample
+// fragments come straight from global memory (32 rows x 32 contiguous bytes per load instruction); the
+// result tile goes back out through LDS in whole rows.  A second K segment lets a layer read its input
 // from two buffers (the colour trunk's first layer: geometry features + the sample row) without a concat.
 //
 // wgrad_kernel.  8 waves hold the whole 256 x 256 fp32 result (64 x 128 per wave = 128 accumulator registers),
@@ -44,7 +45,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kChunkBytes = 256;           // K bytes of one row per chunk
-constexpr int kPitch = kChunkBytes + 16;   // LDS row pitch of the weight chunk
 constexpr int kRowsPerWG = 128;
 
 template <bool BF16>
@@ -96,16 +96,15 @@ struct LinearArgs {
 };
 
 // One output quad of a lane (4 consecutive columns n .. n+3 of row m): bias, ReLU, the optional fp32 side copy.
+// (the bias sits in LDS -- zeros when the layer has none: 32 dependent global loads per lane, each waited for,
+// were the single largest cost of the first version of this epilogue)
 template <int NB>
-__device__ __forceinline__ f32x4 out_quad(const f32x16 (&acc)[NB], int nb, int q, int n, const LinearArgs &a, int64_t m) {
+__device__ __forceinline__ f32x4 out_quad(const f32x16 (&acc)[NB], int nb, int q, int n, const LinearArgs &a, int64_t m,
+                                          const float *bias_lds) {
     f32x4 v;
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_lds + n);
 #pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = acc[nb][4 * q + j];
-    if (a.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; j++) v[j] += b[j];
-    }
+    for (int j = 0; j < 4; j++) v[j] = acc[nb][4 * q + j] + b[j];
     if (a.relu) {
 #pragma unroll
         for (int j = 0; j < 4; j++) v[j] = fmaxf(v[j], 0.0f);
@@ -124,25 +123,39 @@ __device__ __forceinline__ f32x4 out_quad(const f32x16 (&acc)[NB], int nb, int q
 // 32 x N tile through LDS (its own rows only: no workgroup barrier) and writes -- and reads the ReLU mask of the
 // input-gradient form -- in whole rows, 16 bytes per lane, 1 KiB contiguous per instruction.
 template <bool BF16, int NB, int OSZ>
-__device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[NB], const LinearArgs &a, char *wl, int lane, int wave) {
+__device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[NB], const LinearArgs &a, char *wl, const float *bias_lds,
+                                              int lane, int wave) {
     constexpr int ESZ = BF16 ? 2 : 4;
     constexpr int NBP = OSZ == 4 ? (NB < 4 ? NB : 4) : NB;         // 32-column blocks per pass (<= 512 B per row)
     constexpr int OP = NBP * 32 * OSZ + 16;                        // LDS row pitch of the tile
     const int i = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * kRowsPerWG + wave * 32;
     char *ot = wl + wave * 32 * OP;
+    constexpr int ITER = (NBP * 32 * OSZ / 16) / 2;                // 16-byte pieces per lane per pass (32 rows)
 #pragma unroll
     for (int p0 = 0; p0 < NB; p0 += NBP) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int p1 = p0 + NBP < NB ? p0 + NBP : NB;
+        const int ppr = ((p1 - p0) * 32 * OSZ) >> 4;                // 16-byte pieces per row
+        // the ReLU-mask rows of this pass, all in flight before the tile is even written
+        u32x4 mk[ITER];
+        if constexpr (OSZ == ESZ) {
+            if (a.mask) {
+#pragma unroll
+                for (int it = 0; it < ITER; it++) {
+                    const int pc = it * 64 + lane, r = pc / ppr, c = pc - r * ppr;
+                    mk[it] = u32x4{0u, 0u, 0u, 0u};
+                    if (pc < 32 * ppr && m0 + r < a.M)
+                        mk[it] = *reinterpret_cast<const u32x4 *>(a.mask + (m0 + r) * a.ldm + (int64_t)p0 * 32 * OSZ + c * 16);
+                }
+            }
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
             if (nb < p0 || nb >= p1) continue;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int n = nb * 32 + 8 * q + 4 * h;
-                const f32x4 v = out_quad<NB>(acc, nb, q, n, a, m0 + i);
+                const f32x4 v = out_quad<NB>(acc, nb, q, n, a, m0 + i, bias_lds);
                 char *dst = ot + i * OP + (n - p0 * 32) * OSZ;
                 if constexpr (OSZ == 4) {
                     *reinterpret_cast<f32x4 *>(dst) = v;
@@ -155,29 +168,27 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[NB], const Lin
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's own tile: no barrier needed
-        const int ppr = ((p1 - p0) * 32 * OSZ) >> 4;                // 16-byte pieces per row
-        for (int pc = lane; pc < 32 * ppr; pc += 64) {
-            const int r = pc / ppr, c = pc - r * ppr;
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const int pc = it * 64 + lane, r = pc / ppr, c = pc - r * ppr;
             const int64_t row = m0 + r;
-            if (row >= a.M) continue;
+            if (pc >= 32 * ppr || row >= a.M) continue;
             u32x4 v = *reinterpret_cast<const u32x4 *>(ot + r * OP + c * 16);
-            const int64_t colb = (int64_t)p0 * 32 * OSZ + c * 16;
             if constexpr (OSZ == ESZ) {
                 if (a.mask) {
-                    const u32x4 mk = *reinterpret_cast<const u32x4 *>(a.mask + row * a.ldm + colb);
-                    const f32x4 mkf = __builtin_bit_cast(f32x4, mk);      // (whole-vector cast, see mma16)
+                    const f32x4 mkf = __builtin_bit_cast(f32x4, mk[it]);      // (whole-vector cast, see mma16)
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         if constexpr (BF16) {
-                            if (!((int32_t)(mk[e] << 16) > 0)) v[e] &= 0xffff0000u;
-                            if (!((int32_t)(mk[e] & 0xffff0000u) > 0)) v[e] &= 0x0000ffffu;
+                            if (!((int32_t)(mk[it][e] << 16) > 0)) v[e] &= 0xffff0000u;
+                            if (!((int32_t)(mk[it][e] & 0xffff0000u) > 0)) v[e] &= 0x0000ffffu;
                         } else {
                             if (!(mkf[e] > 0.0f)) v[e] = 0u;
                         }
                     }
                 }
             }
-            *reinterpret_cast<u32x4 *>(a.y + row * a.ldy + colb) = v;
+            *reinterpret_cast<u32x4 *>(a.y + row * a.ldy + (int64_t)p0 * 32 * OSZ + c * 16) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // tile read before the next pass overwrites it
     }
@@ -185,7 +196,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[NB], const Lin
 
 template <int NB>
 constexpr int linear_lds_bytes() {
-    constexpr int w = NB * 32 * kPitch;                                   // weight chunk
+    constexpr int w = NB * 32 * kChunkBytes;                              // weight chunk
     constexpr int o = kRowsPerWG * ((NB < 4 ? NB : 4) * 32 * 4 + 16);     // widest epilogue tile (4-byte outputs)
     constexpr int o2 = kRowsPerWG * (NB * 32 * 2 + 16);                   // 2-byte outputs, all columns in one pass
     return w > o ? (w > o2 ? w : o2) : (o > o2 ? o : o2);
@@ -193,12 +204,16 @@ constexpr int linear_lds_bytes() {
 
 template <bool BF16, int NB>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const LinearArgs a) {
-    __shared__ __attribute__((aligned(16))) char wl[linear_lds_bytes<NB>()];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ONE __shared__ object: [weight chunk | epilogue tiles][bias]
+    __shared__ __attribute__((aligned(16))) char wl[linear_lds_bytes<NB>() + NB * 32 * 4];
+    float *bias_lds = reinterpret_cast<float *>(wl + linear_lds_bytes<NB>());
+    if (threadIdx.x < NB * 32) bias_lds[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.0f;   // visible after the first barrier
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int64_t m = (int64_t)blockIdx.x * kRowsPerWG + wave * 32 + i;
     const int64_t ms = m < a.M ? m : a.M - 1;
     const int64_t ldw = (int64_t)a.k0 + a.k1;
+    const unsigned wl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)wl;
 
     f32x16 acc[NB];
 #pragma unroll
@@ -217,22 +232,38 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinearArgs a) {
             const int cb = kb - c0 < kChunkBytes ? kb - c0 : kChunkBytes;
             const int ppr = cb >> 4;                              // 16-byte pieces per weight row
             __syncthreads();                                      // the previous chunk has been read
-            for (int p = threadIdx.x; p < NB * 32 * ppr; p += 256) {
-                const int row = p / ppr, pc = p - row * ppr;
-                *reinterpret_cast<u32x4 *>(wl + row * kPitch + pc * 16) =
-                    *reinterpret_cast<const u32x4 *>(a.W + row * ldw + wcol + c0 + pc * 16);
+            // Weight chunk -> LDS by LDS-DMA (no registers, one L2 round trip for the whole chunk).  A DMA
+            // instruction fills 1 KiB of LDS linearly in lane order = 4 rows x 16 slots of 16 bytes; slot s of
+            // row r receives the chunk's piece s ^ (r & 15) (the swizzle is applied on the SOURCE address), so
+            // that the 16-lane groups of the ds_read_b128 below -- 16 different rows, one piece -- hit 16
+            // different slots.  Pieces beyond a short last chunk are masked off.
+#pragma unroll
+            for (int it = 0; it < NB * 2; it++) {
+                const int rb = wave * (NB * 8) + it * 4;                       // wave-uniform first row
+                const int g = (lane & 15) ^ ((rb + (lane >> 4)) & 15);
+                if (g < ppr) {
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"((unsigned)((lane >> 4) * (int)ldw + g * 16)), "s"(a.W + rb * ldw + wcol + c0),
+                                   "s"(wl_lds + (unsigned)(rb * kChunkBytes))
+                                 : "memory");
+                }
             }
             u32x4 xf[8];
 #pragma unroll
             for (int kg = 0; kg < 8; kg++)
                 if (kg * 32 < cb) xf[kg] = *reinterpret_cast<const u32x4 *>(xrow + c0 + kg * 32);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMAs (invisible to the compiler) and the loads
             __syncthreads();
 #pragma unroll
             for (int kg = 0; kg < 8; kg++) {
                 if (kg * 32 < cb) {
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
-                        const u32x4 w = *reinterpret_cast<const u32x4 *>(wl + (nb * 32 + i) * kPitch + kg * 32 + h * 16);
+                        const u32x4 w = *reinterpret_cast<const u32x4 *>(
+                            wl + (nb * 32 + i) * kChunkBytes + (((2 * kg + h) ^ (i & 15)) << 4));
                         acc[nb] = mma16<BF16>(w, xf[kg], acc[nb]);
                     }
                 }
@@ -245,9 +276,9 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinearArgs a) {
     if (a.n_store == NB * 32 && !(a.mask && BF16 && a.out_f32)) {
         __syncthreads();                                          // every wave is done with the weight chunk
         if (out4)
-            epilogue_rows<BF16, NB, 4>(acc, a, wl, lane, wave);
+            epilogue_rows<BF16, NB, 4>(acc, a, wl, bias_lds, lane, wave);
         else
-            epilogue_rows<BF16, NB, 2>(acc, a, wl, lane, wave);
+            epilogue_rows<BF16, NB, 2>(acc, a, wl, bias_lds, lane, wave);
         return;
     }
     // narrow outputs (the 3 colour logits): direct per-lane stores
@@ -257,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinearArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int n = nb * 32 + 8 * q + 4 * h;
-            f32x4 v = out_quad<NB>(acc, nb, q, n, a, m);
+            f32x4 v = out_quad<NB>(acc, nb, q, n, a, m, bias_lds);
             if (m >= a.M) continue;
             if (a.mask) {
                 const char *mp = a.mask + m * a.ldm + (int64_t)n * ESZ;

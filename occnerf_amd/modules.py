@@ -122,23 +122,33 @@ class _ConvDecoder3D(nn.Module):
     # which take ~31 ms per frame for this 9 GFLOP stack on MI355X.
     _TAPS = (((1, 1), (3, 0)), ((0, 2), (2, 1)))     # parity -> ((kernel index, padded offset), ...)
 
+    def _tap_index(self, device):
+        """Kernel positions (kd*16 + kh*4 + kw) of the 8 taps of each of the 8 output parity classes, flat [64]."""
+        cache = self.__dict__.setdefault('_tap_idx', {})
+        key = str(device)
+        if key not in cache:
+            idx = [(kd * 4 + kh) * 4 + kw for pd in (0, 1) for ph in (0, 1) for pw in (0, 1)
+                   for kd, _ in self._TAPS[pd] for kh, _ in self._TAPS[ph] for kw, _ in self._TAPS[pw]]
+            cache[key] = torch.tensor(idx, dtype=torch.long, device=device)
+        return cache[key]
+
     def _packed_conv_weights(self):
+        """[8 parity, 8 taps x Cin, Cout] per layer: one index_select + one permuted copy each (differentiable, so
+        the same formulation serves the training step; cached per weight version when no graph is being built)."""
         convs = [m for m in self.block_conv if isinstance(m, nn.ConvTranspose3d)]
+        grad = torch.is_grad_enabled() and any(m.weight.requires_grad for m in convs)
         key = tuple((m.weight.data_ptr(), m.weight._version) for m in convs)
-        if getattr(self, '_wp_key', None) != key:
-            packed = []
-            for m in convs:
-                W = m.weight.detach()                                   # [Cin, Cout, 4, 4, 4]
-                per_parity = []
-                for pd in (0, 1):
-                    for ph in (0, 1):
-                        for pw in (0, 1):
-                            taps = [W[:, :, kd, kh, kw] for kd, _ in self._TAPS[pd]
-                                    for kh, _ in self._TAPS[ph] for kw, _ in self._TAPS[pw]]
-                            per_parity.append(torch.cat(taps, 0))       # [8 Cin, Cout]
-                packed.append(torch.stack(per_parity, 0).contiguous())  # [8, 8 Cin, Cout]
-            self._wp, self._wp_key = packed, key
-        return self._wp
+        if not grad and getattr(self, '_wp_key', None) == key:
+            return self._wp
+        packed = []
+        for m in convs:
+            W = m.weight                                                # [Cin, Cout, 4, 4, 4]
+            Cin, Cout = W.shape[:2]
+            sel = W.reshape(Cin, Cout, 64).index_select(2, self._tap_index(W.device))      # [Cin, Cout, (parity, tap)]
+            packed.append(sel.view(Cin, Cout, 8, 8).permute(2, 3, 0, 1).reshape(8, 8 * Cin, Cout))
+        if not grad:
+            self._wp, self._wp_key = [p.detach() for p in packed], key
+        return packed
 
     def _patch_index(self, D, H, Wd, device):
         """Flat indices into the zero-padded [D+2, H+2, W+2] input of the 8 taps of every output parity
@@ -185,9 +195,9 @@ class MotionWeightVolumeDecoder(nn.Module):
 
     def forward(self, motion_weights_priors, **_):
         emb = self.const_embedding[None]
-        if torch.is_grad_enabled() or not emb.is_cuda:       # autograd / CPU: the plain module stack
+        if not emb.is_cuda:                                  # CPU (tests): the plain module stack
             dec = self.decoder(emb)
-        else:                                                # render: same maths as batched GEMMs
+        else:                                                # same maths as batched GEMMs, with or without a graph
             dec = self.decoder.forward_gemm(emb)
         return F.softmax(dec + torch.log(motion_weights_priors), dim=1)
 

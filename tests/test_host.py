@@ -63,6 +63,16 @@ def test_volume_decoder_gemm_formulation_matches_conv_transpose():
         a, b = dec(emb), dec.forward_gemm(emb)
     assert a.shape == b.shape == (1, 25, 32, 32, 32)
     assert (a - b).abs().max() <= 1e-14 * max(1.0, float(a.abs().max()))
+    # and it is the same function of the weights: gradients of every parameter and of the embedding (training)
+    w = torch.randn(1, 25, 32, 32, 32, dtype=torch.float64)
+    grads = []
+    for fn in (dec, dec.forward_gemm):
+        dec.zero_grad(set_to_none=True)
+        e = emb.clone().requires_grad_(True)
+        (fn(e) * w).sum().backward()
+        grads.append([e.grad.clone()] + [p.grad.clone() for p in dec.parameters()])
+    for ga, gb in zip(*grads):
+        assert (ga - gb).abs().max() <= 1e-12 * max(1.0, float(ga.abs().max()))
 
 
 def test_shard_bounds():

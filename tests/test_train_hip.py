@@ -375,3 +375,40 @@ def test_hip_stages_match_torch_autograd_at_size():
     print({k: f'{v:.2e}' for k, v in worst.items()})
     for n, v in worst.items():
         assert v <= 2e-3, (n, v)
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+@pytest.mark.parametrize('clip', [None, 1.0, 1e-3])
+def test_fused_adam_matches_torch(clip):
+    """trainer.py:248-249: clip_grad_norm_ + torch.optim.Adam.step() with per-group learning rates, five steps, on
+    tensors of awkward sizes (chunk boundaries, unaligned tails, a parameter without gradient)."""
+    from occnerf_amd.optim import FusedAdam
+    g = torch.Generator(device='cpu').manual_seed(7)
+    shapes = [(70001,), (256, 68), (3,), (65536 * 2 + 5,), (1,), (1024, 512, 2)]
+    ref = [torch.randn(s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    mine = [p.detach().clone().requires_grad_(True) for p in ref]
+    lrs = [1e-3, 5e-4, 1e-2, 1e-3, 5e-5, 2e-3]
+    o_ref = torch.optim.Adam([{'params': [p], 'lr': lr} for p, lr in zip(ref, lrs)], betas=(0.9, 0.999))
+    o_mine = FusedAdam([{'params': [p], 'lr': lr} for p, lr in zip(mine, lrs)], betas=(0.9, 0.999))
+    for it in range(5):
+        for k, (a, b) in enumerate(zip(ref, mine)):
+            if k == 2 and it < 5:
+                continue                                  # this parameter never receives a gradient
+            gr = torch.randn(a.shape, generator=g).to(DEV) * (10.0 if it == 3 else 0.1)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        if clip is not None:
+            want_norm = torch.nn.utils.clip_grad_norm_(ref, clip)
+        o_ref.step()
+        o_mine.step(max_grad_norm=clip)
+        if clip is not None:
+            assert abs(float(o_mine.grad_norm()) - float(want_norm)) <= 1e-5 * float(want_norm)
+        for grp in o_ref.param_groups + o_mine.param_groups:
+            grp['lr'] *= 0.9                               # what exp_decay.update_lr does between steps
+    for a, b in zip(ref, mine):
+        assert _rel(b.detach(), a.detach()) <= 2e-6
+    sd_ref, sd_mine = o_ref.state_dict(), o_mine.state_dict()
+    assert sorted(sd_ref['state']) == sorted(sd_mine['state'])
+    for k in sd_ref['state']:
+        assert sorted(sd_ref['state'][k]) == sorted(sd_mine['state'][k])
+        assert _rel(sd_mine['state'][k]['exp_avg_sq'], sd_ref['state'][k]['exp_avg_sq']) <= 2e-6
+        assert float(sd_mine['state'][k]['step']) == float(sd_ref['state'][k]['step'])

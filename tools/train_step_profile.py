@@ -18,13 +18,14 @@ for k in ('near', 'far'): frame[k] = frame[k][sel]
 frame['rays'] = frame['rays'][:, sel]
 data = frame_to_device(frame, 'cuda:0')
 params = [p for p in net.parameters() if p.requires_grad]
-opt = torch.optim.Adam(params, lr=1e-4)
+from occnerf_amd.optim import FusedAdam
+opt = FusedAdam(params, lr=1e-4)
 def step():
     opt.zero_grad(set_to_none=True)
     out = net(**data, iter_val=1e7)
     loss = ((out['rgb'] - 0.5) ** 2).mean() + 0.1 * out['comp_loss'].mean()
     loss.backward()
-    opt.step()
+    opt.step(max_grad_norm=1.0)
     return float(loss)
 for i in range(2): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()

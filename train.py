@@ -38,7 +38,8 @@ def make_optimizer(net, tc):
             if key in name:
                 lr = tc[lr_name]
         groups.append({'params': [p], 'lr': lr, 'name': name, 'base_lr': lr})
-    return torch.optim.Adam(groups, lr=tc['lr'], betas=(0.9, 0.999))
+    from occnerf_amd.optim import FusedAdam
+    return FusedAdam(groups, lr=tc['lr'], betas=(0.9, 0.999))
 
 
 def patch_rays(frame, rng, n_patches=6, size=32):
@@ -90,8 +91,7 @@ def main():
             loss = tc['lossweights']['mse'] * torch.mean((out['rgb'].float() - target) ** 2) \
                 + tc['lossweights']['comp'] * out['comp_loss'].float().mean()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)          # trainer.py:248
-        opt.step()
+        opt.step(max_grad_norm=1.0)                                     # trainer.py:248-249: clip + Adam, one device pass
         decay = 0.1 ** (it / (tc['lrate_decay'] * 1000))                # exp_decay.py:7-19
         for grp in opt.param_groups:
             grp['lr'] = grp['base_lr'] * decay
