@@ -355,6 +355,15 @@ int occnerf_warp_backward(const float *rays, int64_t n, int32_t S, const float *
 int occnerf_agg_weights(const float *counter, const int32_t *knn, int64_t N, int32_t K, float *atts, float *var,
                         void *stream);
 
+/* ConvTranspose3d(kernel 4, stride 2, padding 1) of the motion-weight volume decoder (network_util.py:12-50) as GEMM +
+ * gather.  cols[Cout*64, D*H*W] = W.view(Cin, Cout*64)^T x[Cin, D*H*W] (the caller's GEMM) ->
+ * out[Cout, 2D, 2H, 2W] = bias[co] + the <= 8 taps that reach each output voxel (occnerf_convt3d_col2im);
+ * its adjoint dcols[Cout*64, D*H*W] from gy[Cout, 2D, 2H, 2W] (occnerf_convt3d_im2col), after which
+ * dx = W.view(Cin, Cout*64) dcols and dW = x dcols^T are plain GEMMs again.  No atomics, fixed summation order. */
+int occnerf_convt3d_col2im(const float *cols, const float *bias, int32_t Cout, int32_t D, int32_t H, int32_t W,
+                           float *out, void *stream);
+int occnerf_convt3d_im2col(const float *gy, int32_t Cout, int32_t D, int32_t H, int32_t W, float *dcols, void *stream);
+
 /* Optimiser step on the device: the reference's clip_grad_norm_(parameters, max_norm) + torch.optim.Adam.step()
  * (trainer.py:248-249, optimizer.py:12-43) as one multi-tensor pass.  table: n_tensors rows of
  * occnerf_adam_table_row_bytes() = 48 bytes in DEVICE memory, each {float *param; const float *grad; float *exp_avg;

@@ -114,76 +114,60 @@ class _ConvDecoder3D(nn.Module):
     def forward(self, embedding):
         return self.block_conv(self.block_mlp(embedding).view(-1, 1024, 1, 1, 1))
 
-    # ---- GEMM formulation of the same stack (used on the GPU at render time) ----
-    # ConvTranspose3d(k=4, s=2, p=1) maps input voxel i to outputs o = 2i - 1 + k.  Per output
-    # parity the sum has exactly two taps per axis, i.e. each of the 8 parity classes is a
-    # 2x2x2 correlation over the zero-padded input: one batched GEMM [8, DHW, 8 Cin] x
-    # [8, 8 Cin, Cout] per layer (rocBLAS) instead of MIOpen's transposed-convolution kernels,
-    # which take ~31 ms per frame for this 9 GFLOP stack on MI355X.
-    _TAPS = (((1, 1), (3, 0)), ((0, 2), (2, 1)))     # parity -> ((kernel index, padded offset), ...)
-
-    def _tap_index(self, device):
-        """Kernel positions (kd*16 + kh*4 + kw) of the 8 taps of each of the 8 output parity classes, flat [64]."""
-        cache = self.__dict__.setdefault('_tap_idx', {})
-        key = str(device)
-        if key not in cache:
-            idx = [(kd * 4 + kh) * 4 + kw for pd in (0, 1) for ph in (0, 1) for pw in (0, 1)
-                   for kd, _ in self._TAPS[pd] for kh, _ in self._TAPS[ph] for kw, _ in self._TAPS[pw]]
-            cache[key] = torch.tensor(idx, dtype=torch.long, device=device)
-        return cache[key]
-
-    def _packed_conv_weights(self):
-        """[8 parity, 8 taps x Cin, Cout] per layer: one index_select + one permuted copy each (differentiable, so
-        the same formulation serves the training step; cached per weight version when no graph is being built)."""
-        convs = [m for m in self.block_conv if isinstance(m, nn.ConvTranspose3d)]
-        grad = torch.is_grad_enabled() and any(m.weight.requires_grad for m in convs)
-        key = tuple((m.weight.data_ptr(), m.weight._version) for m in convs)
-        if not grad and getattr(self, '_wp_key', None) == key:
-            return self._wp
-        packed = []
-        for m in convs:
-            W = m.weight                                                # [Cin, Cout, 4, 4, 4]
-            Cin, Cout = W.shape[:2]
-            sel = W.reshape(Cin, Cout, 64).index_select(2, self._tap_index(W.device))      # [Cin, Cout, (parity, tap)]
-            packed.append(sel.view(Cin, Cout, 8, 8).permute(2, 3, 0, 1).reshape(8, 8 * Cin, Cout))
-        if not grad:
-            self._wp, self._wp_key = [p.detach() for p in packed], key
-        return packed
-
-    def _patch_index(self, D, H, Wd, device):
-        """Flat indices into the zero-padded [D+2, H+2, W+2] input of the 8 taps of every output parity
-        class: idx[parity, voxel, tap] (cached per input size; one gather then builds all 8 patch matrices
-        of a layer instead of 64 slice copies + 8 concatenations)."""
-        cache = self.__dict__.setdefault('_patch_idx', {})
-        key = (D, H, Wd, str(device))
-        if key not in cache:
-            d, h, w = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(Wd), indexing='ij')
-            per_parity = []
-            for pd in (0, 1):
-                for ph in (0, 1):
-                    for pw in (0, 1):
-                        taps = [((d + od) * (H + 2) + (h + oh)) * (Wd + 2) + (w + ow)
-                                for _, od in self._TAPS[pd] for _, oh in self._TAPS[ph]
-                                for _, ow in self._TAPS[pw]]
-                        per_parity.append(torch.stack([t.reshape(-1) for t in taps], 1))     # [DHW, 8]
-            cache[key] = torch.stack(per_parity, 0).to(device)                                # [8, DHW, 8]
-        return cache[key]
-
+    # ---- GEMM + gather formulation of the same stack (what runs on the GPU, with or without autograd) ----
     def forward_gemm(self, embedding):
         x = self.block_mlp(embedding).view(1024, 1, 1, 1)               # [C, D, H, W], batch 1
         convs = [m for m in self.block_conv if isinstance(m, nn.ConvTranspose3d)]
-        for li, (m, Wp) in enumerate(zip(convs, self._packed_conv_weights())):
-            C, D, H, Wd = x.shape
-            idx = self._patch_index(D, H, Wd, x.device)
-            xp = F.pad(x, (1, 1, 1, 1, 1, 1)).reshape(C, -1)
-            # patches[parity, voxel, tap * C + c] = xp[c, idx[parity, voxel, tap]]
-            patches = xp[:, idx.reshape(-1)].view(C, 8, D * H * Wd, 8).permute(1, 2, 3, 0).reshape(8, D * H * Wd, 8 * C)
-            y = torch.bmm(patches, Wp)                                   # [8, DHW, Cout]
-            Co = y.shape[-1]
-            y = y.view(2, 2, 2, D, H, Wd, Co).permute(6, 3, 0, 4, 1, 5, 2).reshape(Co, 2 * D, 2 * H, 2 * Wd)
-            y = y + m.bias.view(-1, 1, 1, 1)
-            x = F.leaky_relu(y, 0.2) if li < len(convs) - 1 else y
+        for li, m in enumerate(convs):
+            x = conv_transpose3d_k4s2p1(x, m.weight, m.bias)
+            if li < len(convs) - 1:
+                x = F.leaky_relu(x, 0.2)
         return x[None]
+
+
+class _ConvT3dK4S2P1(torch.autograd.Function):
+    """ConvTranspose3d(kernel 4, stride 2, padding 1), batch 1, as cols = W^T x (library GEMM) followed by the HIP
+    gather occnerf_convt3d_col2im; backward = its adjoint gather + two GEMMs (csrc/train_ops.hip).  MIOpen's
+    transposed-convolution kernels take 31 ms (forward) / 4.8 ms (backward) per frame for this 2 GFLOP stack."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import _lib, ops
+        Cin, D, H, W = x.shape
+        Cout = weight.shape[1]
+        x2 = x.reshape(Cin, D * H * W)
+        w2 = weight.reshape(Cin, Cout * 64)
+        cols = torch.mm(w2.t(), x2).contiguous()                        # [Cout*64, DHW]
+        out = torch.empty(Cout, 2 * D, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        with ops._guard(x):
+            rc = _lib.lib().occnerf_convt3d_col2im(ops._chk(cols, torch.float32, 'cols'),
+                                                   ops._opt(bias.detach().contiguous() if bias is not None else None,
+                                                            torch.float32, 'bias'),
+                                                   Cout, D, H, W, out.data_ptr(), ops._stream(x))
+        _lib.check(rc, 'convt3d_col2im')
+        ctx.save_for_backward(x2, w2)
+        ctx.dims = (Cin, Cout, D, H, W, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib, ops
+        x2, w2 = ctx.saved_tensors
+        Cin, Cout, D, H, W, has_bias = ctx.dims
+        gy = gy.contiguous().float()
+        dcols = torch.empty(Cout * 64, D * H * W, device=gy.device, dtype=torch.float32)
+        with ops._guard(gy):
+            rc = _lib.lib().occnerf_convt3d_im2col(gy.data_ptr(), Cout, D, H, W, dcols.data_ptr(), ops._stream(gy))
+        _lib.check(rc, 'convt3d_im2col')
+        dx = torch.mm(w2, dcols).reshape(Cin, D, H, W) if ctx.needs_input_grad[0] else None
+        dw = torch.mm(x2, dcols.t()).reshape(Cin, Cout, 4, 4, 4) if ctx.needs_input_grad[1] else None
+        db = gy.sum(dim=(1, 2, 3)) if has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def conv_transpose3d_k4s2p1(x, weight, bias):
+    """x[Cin,D,H,W] (batch 1), weight[Cin,Cout,4,4,4], bias[Cout] -> [Cout,2D,2H,2W]; GPU fp32 only."""
+    return _ConvT3dK4S2P1.apply(x.float().contiguous(), weight.float(), bias)
 
 
 class MotionWeightVolumeDecoder(nn.Module):

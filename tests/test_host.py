@@ -53,28 +53,6 @@ def test_network_state_dict_surface_on_cpu():
             dst_posevec=torch.zeros(69), near=torch.zeros(4, 1), far=torch.ones(4, 1))
 
 
-def test_volume_decoder_gemm_formulation_matches_conv_transpose():
-    """The render-time GEMM form of the ConvTranspose3d stack is the same function."""
-    from occnerf_amd.modules import _ConvDecoder3D
-    torch.manual_seed(0)
-    dec = _ConvDecoder3D(256, 32, 25).double()
-    emb = torch.randn(1, 256, dtype=torch.float64)
-    with torch.no_grad():
-        a, b = dec(emb), dec.forward_gemm(emb)
-    assert a.shape == b.shape == (1, 25, 32, 32, 32)
-    assert (a - b).abs().max() <= 1e-14 * max(1.0, float(a.abs().max()))
-    # and it is the same function of the weights: gradients of every parameter and of the embedding (training)
-    w = torch.randn(1, 25, 32, 32, 32, dtype=torch.float64)
-    grads = []
-    for fn in (dec, dec.forward_gemm):
-        dec.zero_grad(set_to_none=True)
-        e = emb.clone().requires_grad_(True)
-        (fn(e) * w).sum().backward()
-        grads.append([e.grad.clone()] + [p.grad.clone() for p in dec.parameters()])
-    for ga, gb in zip(*grads):
-        assert (ga - gb).abs().max() <= 1e-12 * max(1.0, float(ga.abs().max()))
-
-
 def test_shard_bounds():
     from occnerf_amd.parallel import shard_bounds
     for n, w in [(262144, 8), (183784, 8), (7, 8), (0, 2), (1000, 3)]:

@@ -412,3 +412,27 @@ def test_fused_adam_matches_torch(clip):
         assert sorted(sd_ref['state'][k]) == sorted(sd_mine['state'][k])
         assert _rel(sd_mine['state'][k]['exp_avg_sq'], sd_ref['state'][k]['exp_avg_sq']) <= 2e-6
         assert float(sd_mine['state'][k]['step']) == float(sd_ref['state'][k]['step'])
+
+
+# ------------------------------------------------------------------------------------------ volume decoder
+def test_volume_decoder_gemm_gather_matches_conv_transpose():
+    """a4: the GEMM + HIP gather form of the ConvTranspose3d stack (deconv_vol_decoder.py:25-33, network_util.py:12-50)
+    is the same function as torch's ConvTranspose3d modules -- output, and the gradients of every parameter and of the
+    embedding (fp32 both sides: 2e-5 of the largest entry)."""
+    from occnerf_amd.modules import _ConvDecoder3D
+    torch.manual_seed(0)
+    dec = _ConvDecoder3D(256, 32, 25).to(DEV)
+    emb = torch.randn(1, 256, device=DEV)
+    w = torch.randn(1, 25, 32, 32, 32, device=DEV)
+    outs, grads = [], []
+    for fn in (dec, dec.forward_gemm):
+        dec.zero_grad(set_to_none=True)
+        e = emb.clone().requires_grad_(True)
+        y = fn(e)
+        (y * w).sum().backward()
+        outs.append(y.detach())
+        grads.append([e.grad.clone()] + [p.grad.clone() for p in dec.parameters()])
+    assert outs[0].shape == outs[1].shape == (1, 25, 32, 32, 32)
+    assert _rel(outs[1], outs[0]) <= 2e-5
+    for ga, gb in zip(*grads):
+        assert _rel(gb, ga) <= 2e-5
