@@ -1,11 +1,17 @@
 """Multi-GPU: rays shard, one process per GPU, one gather per frame.
 
-Rays are independent (the only cross-sample dependency is the scan inside one ray), so the
-`ray_mask`-compacted ray list is cut into `world_size` contiguous blocks; every rank holds the
-full (61 MiB) model, renders its block with no data-path collective, and the `[R/N, 5]`
-(rgb, alpha, depth) blocks are gathered on rank 0 over RCCL/xGMI (<= 5.2 MB per 512^2 frame:
-latency-bound, one collective).  This replaces the reference's nn.DataParallel over *samples*
-with its per-call weight broadcast (network.py:68-72,142-146), it does not mirror it.
+Rays are independent (the only cross-sample dependency is the scan inside one ray), so a frame's
+`ray_mask`-compacted ray list is dealt to the ranks in chunks of 4 096 consecutive rays; every rank holds the
+full (61 MiB) model, renders its rays with no data-path collective, and the `[R/N, 5]` (rgb, alpha, depth)
+blocks are gathered on rank 0 over RCCL/xGMI (<= 5.2 MB per 512^2 frame: latency-bound, one collective).
+This replaces the reference's nn.DataParallel over *samples* with its per-call weight broadcast
+(network.py:68-72,142-146); it does not mirror it.
+
+`ShardedRenderer` keeps everything that does not change from frame to frame -- the shard index lists, the
+un-permutation that puts the gathered blocks back into the caller's ray order, the padded send / receive
+buffers (two slots) -- and issues the gather asynchronously, so that frame t's gather runs under frame t+1's
+kernels (`render_frames`).  A rank whose shard is empty (fewer rays than ranks x chunk) skips the render and
+still takes part in the gather.
 """
 import torch
 import torch.distributed as dist
@@ -58,32 +64,111 @@ def gather_rays(block, n_rays, dst=0, group=None):
     return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, bounds)], 0)
 
 
+class _Pending:
+    """One frame in flight: the gather's work handle and the slot holding its buffers."""
+    __slots__ = ('work', 'slot', 'n_rays', 'local')
+
+    def __init__(self, work, slot, n_rays, local):
+        self.work, self.slot, self.n_rays, self.local = work, slot, n_rays, local
+
+
+class ShardedRenderer:
+    """Renders frames with their rays sharded over the ranks of `group` (see the module docstring)."""
+
+    def __init__(self, net, device, group=None, chunk=4096, channels=5, single=False):
+        """single: ignore the process group, this process renders whole frames by itself."""
+        self.net, self.device, self.group, self.chunk, self.channels = net, torch.device(device), group, int(chunk), channels
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() and not single else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self._plan = None
+        self._turn = 0
+
+    def formed_world_size(self):
+        """World size the process group actually formed (what bench.py prints)."""
+        return self.world
+
+    def _get_plan(self, R):
+        if self._plan is not None and self._plan['R'] == R:
+            return self._plan
+        shards = [shard_indices(R, r, self.world, self.chunk) for r in range(self.world)]
+        sizes = [int(s.numel()) for s in shards]
+        width = max(max(sizes), 1)
+        plan = {'R': R, 'mine_cpu': shards[self.rank], 'mine_dev': shards[self.rank].to(self.device), 'sizes': sizes,
+                'width': width,
+                'send': [torch.zeros(width, self.channels, device=self.device) for _ in range(2)]}
+        if self.rank == 0 and self.world > 1:
+            # position in the concatenated [world * width] receive buffer of every ray of the frame
+            src = torch.empty(R, dtype=torch.long)
+            for r, s in enumerate(shards):
+                src[s] = r * width + torch.arange(sizes[r])
+            plan['unpermute'] = src.to(self.device)
+            plan['recv'] = [torch.empty(self.world * width, self.channels, device=self.device) for _ in range(2)]
+        self._plan = plan
+        return plan
+
+    def submit(self, data, iter_val=1e7, **net_kwargs):
+        """Render this rank's share of the frame `data` and start the gather of (rgb, alpha, depth).  Per-ray entries
+        (rays[2,R,3], near/far[R,1]) may live on the host (only the shard is then copied to the device) or on the
+        device; every rank passes the same frame."""
+        R = int(data['rays'].shape[1])
+        plan = self._get_plan(R)
+        slot = self._turn = self._turn ^ 1
+        mine = plan['mine_dev'] if data['rays'].is_cuda else plan['mine_cpu']
+        n_mine = plan['sizes'][self.rank]
+        send = plan['send'][slot]
+        if n_mine:
+            local = dict(data)
+            local['rays'] = data['rays'][:, mine].to(self.device, non_blocking=True)
+            local['near'] = data['near'][mine].to(self.device, non_blocking=True)
+            local['far'] = data['far'][mine].to(self.device, non_blocking=True)
+            for k, v in data.items():
+                if k not in ('rays', 'near', 'far') and torch.is_tensor(v) and not v.is_cuda and v.numel() > 3:
+                    local[k] = v.to(self.device, non_blocking=True)
+            out = self.net(**local, iter_val=iter_val, **net_kwargs)
+            send[:n_mine, :3] = out['rgb']
+            send[:n_mine, 3] = out['alpha']
+            send[:n_mine, 4] = out['depth']
+        if self.world == 1:
+            return _Pending(None, slot, R, None)
+        recv = list(plan['recv'][slot].view(self.world, plan['width'], self.channels).unbind(0)) if self.rank == 0 else None
+        work = dist.gather(send, recv, dst=0, group=self.group, async_op=True)
+        return _Pending(work, slot, R, None)
+
+    def finish(self, pending):
+        """Wait for a frame's gather; -> {'rgb','alpha','depth'} in the caller's ray order on rank 0, None elsewhere."""
+        plan = self._get_plan(pending.n_rays)
+        if self.world == 1:
+            full = plan['send'][pending.slot][:pending.n_rays]
+        else:
+            pending.work.wait()
+            if self.rank != 0:
+                return None
+            full = plan['recv'][pending.slot].index_select(0, plan['unpermute'])
+        return {'rgb': full[:, :3], 'alpha': full[:, 3], 'depth': full[:, 4]}
+
+    def render_frames(self, frames, iter_val=1e7, **net_kwargs):
+        """Generator over `frames`: frame t's gather overlaps frame t+1's kernels (one frame of lag)."""
+        prev = None
+        for data in frames:
+            cur = self.submit(data, iter_val=iter_val, **net_kwargs)
+            if prev is not None:
+                yield self.finish(prev)
+            prev = cur
+        if prev is not None:
+            yield self.finish(prev)
+
+
+_renderers = {}
+
+
 def render_frame_sharded(net, data, iter_val=1e7, group=None, chunk=4096):
-    """Render this rank's share of `data` (chunks of `chunk` rays dealt round-robin, see shard_indices) and
-    gather (rgb, alpha, depth) on rank 0 -- the path's only collective.  Returns the full-frame dict in the
-    caller's ray order on rank 0 and None on the other ranks."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    R = data['rays'].shape[1]
+    """One frame, synchronously: this rank's share rendered, (rgb, alpha, depth) gathered on rank 0 -- the path's
+    only collective.  Returns the full-frame dict in the caller's ray order on rank 0 and None on the other ranks."""
     dev = data['rays'].device
-    mine = shard_indices(R, rank, world, chunk).to(dev)
-    local = dict(data)
-    local['rays'] = data['rays'][:, mine]
-    local['near'], local['far'] = data['near'][mine], data['far'][mine]
-    out = net(**local, iter_val=iter_val)
-    packed = torch.cat([out['rgb'], out['alpha'][:, None], out['depth'][:, None]], dim=1)
-    if world == 1:
-        full = packed
-    else:
-        sizes = [int(shard_indices(R, r, world, chunk).numel()) for r in range(world)]
-        width = max(sizes)
-        padded = packed.new_zeros((width, packed.shape[1]))
-        padded[:packed.shape[0]] = packed
-        bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
-        dist.gather(padded, bufs, dst=0, group=group)
-        if rank != 0:
-            return None
-        full = packed.new_empty((R, packed.shape[1]))
-        for r in range(world):
-            full[shard_indices(R, r, world, chunk).to(dev)] = bufs[r][:sizes[r]]
-    return {'rgb': full[:, :3], 'alpha': full[:, 3], 'depth': full[:, 4]}
+    if dev.type != 'cuda' and hasattr(net, 'point_base'):      # host frame: the shard is copied to the model's device
+        dev = net.point_base.device
+    key = (id(net), str(dev), id(group), int(chunk))
+    r = _renderers.get(key)
+    if r is None:
+        r = _renderers[key] = ShardedRenderer(net, dev, group=group, chunk=chunk)
+    return r.finish(r.submit(data, iter_val=iter_val))

@@ -721,3 +721,35 @@ def test_live_rows_and_scatter(ops, n):
     ref = torch.zeros(n, 5, device=DEV)
     ref[want.long()] = raw_c[:m]
     assert torch.equal(full, ref)
+
+
+def _torchrun(script_args, nproc, timeout=900):
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port)] + script_args
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    import json
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert lines, res.stdout[-2000:] + res.stderr[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs 2 GPUs on the node (config 3: rays sharded over RCCL)')
+def test_two_rank_sharded_render_over_rccl():
+    """BASELINE configs[2]: rays of one frame sharded over 2 ranks (child processes started by the launcher; RCCL
+    gather, pipelined) == the frame rendered by one rank, bit for bit; and bench.py --gpus 2 runs and reports strong
+    scaling with the world size RCCL formed."""
+    got = _torchrun(['tools/sharded_check.py'], 2)
+    assert got['world_size_formed'] == 2 and got['bit_identical'], got
+    line = _torchrun(['bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-alt', '--no-cpu-baseline'], 2)
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['world_size_formed'] == 2
+    assert line['value'] > 0

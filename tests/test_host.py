@@ -94,13 +94,24 @@ def _gloo_worker(rank, world, port, n_rays, q):
     g = torch.Generator().manual_seed(0)
     data = {'rays': torch.rand(2, n_rays, 3, generator=g), 'near': torch.rand(n_rays, 1, generator=g),
             'far': torch.rand(n_rays, 1, generator=g)}
+    def check(out, d):
+        return (torch.equal(out['rgb'], d['rays'][0] * 2.0) and torch.equal(out['alpha'], d['near'][:, 0] + 1.0)
+                and torch.equal(out['depth'], d['far'][:, 0] * 3.0))
     out = render_frame_sharded(FakeNet(), data, chunk=96)
+    ok = check(out, data) if rank == 0 else out is None
+    # pipelined: frame t's gather is waited for after frame t+1 has been submitted (two buffer slots, reused)
+    from occnerf_amd.parallel import ShardedRenderer
+    frames = [{k: v * (1.0 + 0.25 * t) for k, v in data.items()} for t in range(5)]
+    r = ShardedRenderer(FakeNet(), 'cpu', chunk=96)
+    assert r.formed_world_size() == world
+    outs = list(r.render_frames(frames))
+    assert len(outs) == 5
+    for o, d in zip(outs, frames):
+        ok = ok and (check(o, d) if rank == 0 else o is None)
     if rank == 0:
-        ok = (torch.equal(out['rgb'], data['rays'][0] * 2.0) and torch.equal(out['alpha'], data['near'][:, 0] + 1.0)
-              and torch.equal(out['depth'], data['far'][:, 0] * 3.0))
         q.put(bool(ok))
     else:
-        assert out is None
+        assert ok
     dist.barrier()
     dist.destroy_process_group()
 
