@@ -723,6 +723,110 @@ def test_live_rows_and_scatter(ops, n):
     assert torch.equal(full, ref)
 
 
+def test_skip_empty_samples_is_exact_at_bench_size(ops):
+    """The same property on the frame the headline is quoted on (BASELINE configs[1]: 512x512 rays, 128 samples,
+    random-init checkpoint, non-rigid on): skipping the dead quarter of the samples changes no output bit."""
+    from occnerf_amd import synth
+    net, ctx = build_network(seed=0, amplify=False, S=128, non_rigid=True)
+    frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
+    data = frame_to_device(frame, DEV)
+    outs = []
+    for skip in (True, False):
+        net.cfg.skip_empty_samples = skip
+        with torch.no_grad():
+            o = net(**data, iter_val=1e7)
+        outs.append({k: o[k].clone() for k in ('rgb', 'alpha', 'depth')})
+        if skip:
+            live = int(net.last_live_count)
+    net.cfg.skip_empty_samples = True
+    R = frame['rays'].shape[1]
+    assert 0.5 * R * 128 < live < 0.9 * R * 128, live          # a real fraction of the frame is dead
+    for k in ('rgb', 'alpha', 'depth'):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_config1_real_size(oracle):
+    """BASELINE configs[0] at its real size: T-pose render, 128x128 image, 32 samples/ray, random-init weights --
+    every ray against the full CPU oracle (1e-4, the BASELINE gate)."""
+    from occnerf_amd import synth
+    net, ctx = build_network(seed=0, amplify=False, S=32, non_rigid=False)
+    frame = synth.make_frame(img_size=128, pose72=np.zeros(72, np.float32), orbit_frame=0)
+    R = frame['rays'].shape[1]
+    assert R > 4000
+    with torch.no_grad():
+        out = net(**frame_to_device(frame, DEV), iter_val=1e7)
+    want = stagewise_oracle_render(None, ctx, frame=frame, S=32, non_rigid=False)
+    for k in ('rgb', 'alpha', 'depth'):
+        assert out[k].shape[0] == R
+        assert np.abs(out[k].cpu().numpy() - want[k]).max() <= 1e-4, k
+
+
+def test_config4_full_frame(oracle):
+    """BASELINE configs[3] as written: one full 1024x1024 x 192-sample frame (734 K rays, 141 M samples, three passes of
+    the memory-bounded route), non-rigid on, seeded visibility counts (the occlusion-aware aggregation): finite,
+    deterministic, a 4 096-ray slice rendered alone is bit-identical, 96 rays against the full CPU oracle."""
+    from occnerf_amd import synth
+    net, ctx = build_network(seed=0, amplify=False, S=192, non_rigid=True)
+    rng = np.random.RandomState(4)
+    pc = ctx['point_base']
+    cnt = np.where(pc[:, 2] > 0, 1.0, 1.0 + rng.poisson(50, pc.shape[0])).astype(np.float32)
+    net.point_counter.data.copy_(torch.from_numpy(cnt).to(DEV))
+    frame = synth.make_frame(img_size=1024, pose72=synth.seeded_pose(1), orbit_frame=28)
+    data = frame_to_device(frame, DEV)
+    R = frame['rays'].shape[1]
+    rays_per_pass = int(net.cfg.get('max_samples_per_pass', 1 << 26)) // 192
+    assert -(-R // rays_per_pass) >= 3                                # the memory-bounded route really runs in 3 passes
+    with torch.no_grad():
+        out = net(**data, iter_val=1e7)
+        assert all(bool(torch.isfinite(out[k]).all()) for k in ('rgb', 'alpha', 'depth'))
+        out2 = net(**data, iter_val=1e7)
+        for k in ('rgb', 'alpha', 'depth'):
+            assert torch.equal(out[k], out2[k]), k
+        lo = R // 2
+        part = dict(data)
+        part['rays'], part['near'], part['far'] = data['rays'][:, lo:lo + 4096].contiguous(), data['near'][lo:lo + 4096], \
+            data['far'][lo:lo + 4096]
+        outp = net(**part, iter_val=1e7)
+        for k in ('rgb', 'alpha', 'depth'):
+            assert torch.equal(outp[k], out[k][lo:lo + 4096]), k
+    sel = np.sort(np.random.RandomState(1).choice(R, 96, replace=False))
+    sub = dict(frame)
+    sub['rays'], sub['near'], sub['far'] = frame['rays'][:, sel], frame['near'][sel], frame['far'][sel]
+    octx = dict(ctx)
+    octx['counter'] = cnt
+    want = stagewise_oracle_render(None, octx, frame=sub, S=192, non_rigid=True)
+    for k in ('rgb', 'alpha', 'depth'):
+        assert np.abs(out[k].cpu().numpy()[sel] - want[k]).max() <= 1e-4, k
+    assert float(out['alpha'].max()) > 0.05
+
+
+@pytest.mark.parametrize('name', util.GOLDEN_CASES)
+def test_per_frame_modules_on_gpu_against_reference(name):
+    """Rows a2-a4 on the GPU, directly against what the reference's own modules produced (goldens recorded by
+    oracle/ref_harness/make_golden.py): pose refiner -> `pose.Rs`, motion bases -> `mb.Rs`, `mb.Ts`, motion-weight
+    volume (the GEMM + HIP gather decoder) -> `mw.vol_slice`, `mw.vol_sum`."""
+    from tests.gpu_util import golden_frame
+    g = util.load_golden(name)
+    net, ctx = build_network(int(g['meta.seed']), bool(int(g['meta.amplify'])), S=int(g['meta.S']),
+                             non_rigid=bool(int(g['meta.non_rigid'])))
+    frame = golden_frame(g)
+    d = frame_to_device(frame, DEV)
+    with torch.no_grad():
+        posevec = d['dst_posevec'][None]
+        dst_Rs, dst_Ts = d['dst_Rs'][None], d['dst_Ts'][None]
+        if 'pose.Rs' in g:
+            refined = net.pose_decoder(posevec)['Rs']
+            assert np.abs(refined.cpu().numpy() - g['pose.Rs']).max() <= 1e-6
+            no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3), refined.reshape(-1, 3, 3)).reshape(-1, 23, 3, 3)
+            dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
+        Rs, Ts = net.motion_basis_computer(dst_Rs, dst_Ts, d['cnl_gtfms'][None])
+        assert np.abs(Rs.cpu().numpy() - g['mb.Rs']).max() <= 2e-6
+        assert np.abs(Ts.cpu().numpy() - g['mb.Ts']).max() <= 2e-6
+        vol = net.mweight_vol_decoder(motion_weights_priors=d['motion_weights_priors'][None])[0]
+        assert np.abs(vol[:, ::4, ::4, ::4].cpu().numpy() - g['mw.vol_slice']).max() <= 1e-5
+        assert abs(float(vol.double().sum()) - float(g['mw.vol_sum'])) <= 1e-3 * abs(float(g['mw.vol_sum']))
+
+
 def _torchrun(script_args, nproc, timeout=900):
     import socket
     import subprocess
