@@ -355,6 +355,13 @@ int occnerf_warp_backward(const float *rays, int64_t n, int32_t S, const float *
 int occnerf_agg_weights(const float *counter, const int32_t *knn, int64_t N, int32_t K, float *atts, float *var,
                         void *stream);
 
+/* Image assembly after the renderer, run.py:46-63 (unpack_to_image) + image_util.py:19-20 (to_8b_image) in one kernel:
+ * out_rgb[H*W*3] = uint8(255 * clip(x, 0, 1)) of the ray's colour where a ray exists, of h_bgcolor01[3] (HOST,
+ * cfg.bgcolor / 255 as float32) elsewhere; out_alpha[H*W*3] (optional) the same for alpha, replicated to 3 channels,
+ * 0 where no ray.  ray_index[R]: ascending flat pixel index of every ray (nonzero(ray_mask)), int64. */
+int occnerf_assemble_image(const float *rgb, const float *alpha, const int64_t *ray_index, int64_t R, int32_t height,
+                           int32_t width, const float *h_bgcolor01, uint8_t *out_rgb, uint8_t *out_alpha, void *stream);
+
 /* ConvTranspose3d(kernel 4, stride 2, padding 1) of the motion-weight volume decoder (network_util.py:12-50) as GEMM +
  * gather.  cols[Cout*64, D*H*W] = W.view(Cin, Cout*64)^T x[Cin, D*H*W] (the caller's GEMM) ->
  * out[Cout, 2D, 2H, 2W] = bias[co] + the <= 8 taps that reach each output voxel (occnerf_convt3d_col2im);

@@ -69,6 +69,7 @@ SIGNATURES = {
     'occnerf_warp_backward_slices': (_i32, [_i64]),
     'occnerf_warp_backward': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_agg_weights': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    'occnerf_assemble_image': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     'occnerf_convt3d_col2im': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'occnerf_convt3d_im2col': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'occnerf_adam_table_row_bytes': (_i32, []),

@@ -67,47 +67,55 @@ def _render(data_type, folder_name):
     model = load_network(model).eval()
     writer = ImageWriter(output_dir=os.path.join(cfg.logdir, str(cfg.load_net).replace(':', '_')),
                          exp_name=folder_name) if rank == 0 else None
-    t_render, n_rays, t_first, n_first = 0.0, 0, 0.0, 0
+    n_rays, t_first, n_first = 0, 0.0, 0
+    host_keys = ('bgcolor', 'cnl_bbox_min_xyz', 'cnl_bbox_max_xyz', 'cnl_bbox_scale_xyz')   # float[3]: taken by value
+    torch.cuda.synchronize()
     t_wall0 = time.perf_counter()
+    idx = -1
     for idx, batch in enumerate(loader):
         batch = {k: (v[0] if torch.is_tensor(v) or isinstance(v, list) else v) for k, v in batch.items()}
-        data = {k: v.cuda() for k, v in batch.items() if k not in EXCLUDE_KEYS_TO_GPU and torch.is_tensor(v)}
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        data = {k: (v if k in host_keys else v.cuda(non_blocking=True)) for k, v in batch.items()
+                if k not in EXCLUDE_KEYS_TO_GPU and torch.is_tensor(v)}
         if 'rays' not in batch:          # cfg.device_rays: the ray batch is generated on the GPU (occnerf_amd/rays.py)
             fr = frame_rays(batch['camera_K'].numpy(), batch['camera_E'].numpy(), int(batch['img_height']),
                             int(batch['img_width']), batch['dst_bbox_min'].numpy(), batch['dst_bbox_max'].numpy(),
                             'cuda')
             data.update(rays=fr['rays'], near=fr['near'], far=fr['far'])
             ray_index = torch.nonzero(fr['ray_mask']).squeeze(1)
-        else:
-            ray_index = torch.nonzero(batch['ray_mask'].cuda()).squeeze(1)
+        else:                            # host mask: the index list is formed on the host, no device round trip
+            ray_index = torch.nonzero(batch['ray_mask']).squeeze(1).cuda(non_blocking=True)
+        # a movement sequence is shot by one camera: the renderer's Morton ray order is computed once
+        order_key = ('movement', int(ray_index.numel())) if data_type == 'movement' else None
         with torch.no_grad():
             out = render_frame_sharded(model, data, iter_val=cfg.eval_iter) if world > 1 else \
-                model(**data, iter_val=cfg.eval_iter)
+                model(**data, iter_val=cfg.eval_iter, ray_order_key=order_key)
         if out is None:                               # ranks > 0: their rays went to rank 0
             continue
         rgb_img, alpha_img = assemble_uint8_device(int(batch['img_width']), int(batch['img_height']), ray_index,
-                                                   np.array(cfg.bgcolor) / 255., out['rgb'], out['alpha'])
-        imgs = [rgb_img] + ([alpha_img] if cfg.show_alpha else [])
-        img_out = torch.cat(imgs, dim=1).cpu().numpy()        # uint8 over PCIe
-        dt = time.perf_counter() - t0
-        t_render += dt
+                                                   np.array(cfg.bgcolor) / 255., out['rgb'], out['alpha'],
+                                                   want_alpha=bool(cfg.show_alpha))
+        img_dev = torch.cat([rgb_img, alpha_img], dim=1) if cfg.show_alpha else rgb_img
+        # uint8 over PCIe into a pinned staging buffer; the writer thread waits for the copy and encodes the PNG
+        # while the next frame renders (nothing here blocks on the GPU)
+        writer.append_device(img_dev, img_name=f'{idx:06d}' if data_type == 'movement' else None)
         n_rays += int(ray_index.numel())
         if idx == 0:                                   # includes weight packing and the per-model kNN layout
-            t_first, n_first = dt, int(ray_index.numel())
-        writer.append(img_out, img_name=f'{idx:06d}' if data_type == 'movement' else None)
+            torch.cuda.synchronize()
+            t_first, n_first = time.perf_counter() - t_wall0, int(ray_index.numel())
     if world > 1:
         torch.distributed.barrier()
         if rank != 0:
             torch.distributed.destroy_process_group()
             return
+    torch.cuda.synchronize()
+    t_render = time.perf_counter() - t_wall0
     writer.finalize()
-    print(f'{n_rays} rays in {t_render:.3f} s -> {n_rays / max(t_render, 1e-9):.0f} rays/s (PNG writing excluded)')
+    print(f'{n_rays} rays in {t_render:.3f} s -> {n_rays / max(t_render, 1e-9):.0f} rays/s (frame generation and image '
+          f'assembly included; PNG encoding runs beside it)')
     if idx > 0:
         print(f'first frame {t_first * 1e3:.0f} ms; frames 2..{idx + 1}: '
-              f'{(n_rays - n_first) / max(t_render - t_first, 1e-9):.0f} rays/s; wall clock with frame generation and '
-              f'PNG writing {time.perf_counter() - t_wall0:.2f} s')
+              f'{(n_rays - n_first) / max(t_render - t_first, 1e-9):.0f} rays/s; wall clock with PNG writing '
+              f'{time.perf_counter() - t_wall0:.2f} s')
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -13,14 +13,50 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_unpack_to_image_byte_identical():
-    from occnerf_amd.image import assemble_uint8_device, unpack_to_image
+    from occnerf_amd.image import unpack_to_image
     g = util.load_golden('tpose_ri_image32')
     rgb_img, alpha_img, _ = unpack_to_image(32, 32, g['in.ray_mask'], g['img.bgcolor'], g['out.rgb'], g['out.alpha'])
     assert np.array_equal(rgb_img, g['img.rgb']) and np.array_equal(alpha_img, g['img.alpha'])
-    idx = torch.nonzero(torch.from_numpy(g['in.ray_mask'])).squeeze(1)
-    q, qa = assemble_uint8_device(32, 32, idx, g['img.bgcolor'], torch.from_numpy(g['out.rgb']),
-                                  torch.from_numpy(g['out.alpha']))
-    assert np.array_equal(q.numpy(), g['img.rgb']) and np.array_equal(qa.numpy(), g['img.alpha'])
+
+
+@pytest.mark.gpu
+def test_assemble_image_kernel_byte_identical(tmp_path):
+    """Row f3: the HIP image kernel (scatter by ray_mask + background fill + uint8 quantisation) on device tensors
+    against the reference's own unpack_to_image output; edge values of the quantiser; the asynchronous PNG writer."""
+    from PIL import Image
+    from occnerf_amd.image import ImageWriter, assemble_uint8_device, unpack_to_image
+    g = util.load_golden('tpose_ri_image32')
+    dev = 'cuda:0'
+    idx = torch.nonzero(torch.from_numpy(g['in.ray_mask'])).squeeze(1).to(dev)
+    q, qa = assemble_uint8_device(32, 32, idx, g['img.bgcolor'], torch.from_numpy(g['out.rgb']).to(dev),
+                                  torch.from_numpy(g['out.alpha']).to(dev))
+    assert q.is_cuda and q.dtype == torch.uint8
+    assert np.array_equal(q.cpu().numpy(), g['img.rgb']) and np.array_equal(qa.cpu().numpy(), g['img.alpha'])
+    # quantiser edges and a sparse / empty mask at a non-square size, against the host function
+    rng = np.random.RandomState(0)
+    H, W = 37, 53
+    for frac in (0.0, 0.02, 1.0):
+        mask = rng.rand(H * W) < frac
+        R = int(mask.sum())
+        rgb = rng.rand(R, 3).astype(np.float32) * 1.4 - 0.2
+        alpha = rng.rand(R).astype(np.float32) * 1.2 - 0.1
+        if R > 8:
+            rgb[:8, 0] = [0.0, 1.0, 1.0 / 255, 0.99999994, 254.5 / 255, 0.5, -0.0, 2.0]
+        bg = np.array([255, 128, 3]) / 255.
+        want_rgb, want_a, _ = unpack_to_image(W, H, mask, bg, rgb, alpha)
+        ridx = torch.nonzero(torch.from_numpy(mask)).squeeze(1).to(dev)
+        q, qa = assemble_uint8_device(W, H, ridx, bg, torch.from_numpy(rgb).to(dev), torch.from_numpy(alpha).to(dev))
+        assert np.array_equal(q.cpu().numpy(), want_rgb) and np.array_equal(qa.cpu().numpy(), want_a), frac
+    w = ImageWriter(str(tmp_path), 'seq', stages=2)
+    imgs = []
+    for t in range(5):                                      # more frames than staging buffers
+        img = torch.full((16, 24, 3), 10 * t, dtype=torch.uint8, device=dev)
+        img[t, t] = 255
+        imgs.append(img.cpu().numpy())
+        w.append_device(img)
+    w.finalize()
+    for t, want in enumerate(imgs):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / 'seq' / f'{t:06d}.png')), want)
 
 
 @pytest.mark.gpu

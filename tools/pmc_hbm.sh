@@ -23,7 +23,7 @@ for which in ('fetch', 'write'):
 line = [l for l in open(f'{d}/fetch.log').read().splitlines() if l.startswith('{')]
 n = None
 if line:
-    j = json.loads(line[-1]); n = int(j['config'].get('samples_evaluated_per_frame', j['config']['rays_per_frame'] * j['config']['samples_per_ray']))
+    j = json.loads(line[-1]); n = int(j['config'].get('samples_evaluated_per_launch', j['config'].get('samples_evaluated_per_frame', j['config']['rays_per_frame'] * j['config']['samples_per_ray'])))
 res = {'source': 'tools/pmc_hbm.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), '
                  'bench.py --steps 2 --warmup 1 on MI355X',
        'units': 'counter values are KiB per launch (mean over the launches); FETCH_SIZE x2 for wide coalesced '
