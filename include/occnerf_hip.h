@@ -60,6 +60,15 @@ int occnerf_grid_encode_backward(const float *grad, const float *inputs, const f
                                  const float *dy_dx, float *grad_inputs, uint32_t gridtype,
                                  int align_corners, uint32_t interp, void *stream);
 
+/* occnerf_grid_encode_forward with the level offsets also given as a HOST array h_offsets[L+1]: the D = 4, C = 2 hash
+ * encoder without dy_dx (what the canonical MLP evaluates on every sample) then runs as 8 lanes per sample x 2 levels
+ * per lane with the per-level index mode (dense / power-of-two mask / generic) decided on the host; identical
+ * results.  Everything else falls through to the reference-shaped kernel. */
+int occnerf_grid_encode_forward_h(const float *inputs, const float *embeddings, const int32_t *offsets,
+                                  const int32_t *h_offsets, float *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                  float S, uint32_t H, float *dy_dx, uint32_t gridtype, int align_corners,
+                                  uint32_t interp, void *stream);
+
 /* occnerf_grid_encode_backward with the level offsets also given as a HOST array h_offsets[L+1].  The
  * reference's signature above cannot know the level sizes without reading device memory, so it always runs
  * the atomic scatter (gridencoder.cu:248-340 as written); with the host copy, large D = 4, C = 2 hash batches

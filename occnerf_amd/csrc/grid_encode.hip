@@ -128,6 +128,35 @@ __global__ __launch_bounds__(256) void grid_forward_kernel(
     }
 }
 
+// The encoder the canonical MLP uses (D = 4, C = 2, hash grid, linear interpolation, no input gradient), shaped for
+// this machine instead of the reference's thread-per-(sample, level) grid: 8 lanes share a sample and take 2 levels
+// each (occ::encode_level_d4c2: shared partial corner weights, per-level index mode decided on the HOST -- dense /
+// power-of-two mask / generic -- so the 35-instruction urem of the generic path never runs for this layout), the
+// sample's 16 bytes are read once per lane group instead of once per level, and a wave writes 8 samples x 16 levels.
+// Same results bit for bit as grid_forward_kernel (and as the fused copy inside features.hip).
+__global__ __launch_bounds__(256) void grid_forward_d4c2_kernel(const float4 *__restrict__ inputs,
+                                                                const float2 *__restrict__ embeddings,
+                                                                const int32_t *__restrict__ offsets, float2 *__restrict__ outputs,
+                                                                uint32_t B, uint32_t L, GridLevels lv, GridModes4 gm) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t >> 3, j = t & 7;
+    if (b >= B) return;
+    const float4 xv = inputs[b];
+    const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+    const bool oob = x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f || x[2] < 0.f || x[2] > 1.f || x[3] < 0.f || x[3] > 1.f;
+#pragma unroll
+    for (uint32_t u = 0; u < 2; u++) {
+        const uint32_t l = 2 * j + u;
+        if (l >= L) continue;
+        float2 v = make_float2(0.f, 0.f);                       // gridencoder.cu:118-135: rows outside [0,1] encode to zero
+        if (!oob) {
+            const uint32_t o0 = (uint32_t)offsets[l];
+            v = encode_level_d4c2(x, embeddings, (uint32_t)offsets[l + 1] - o0, lv.scale[l], lv.resolution[l], gm.mode[l], o0);
+        }
+        outputs[(size_t)l * B + b] = v;
+    }
+}
+
 // gridencoder.cu:248-340.  One thread per (sample, level); all C channels of a corner are
 // added by the same thread (C <= 8), fp32 atomics into the zero-initialised gradient table.  (Used for small
 // batches and the general D/C/gridtype cases; large D = 4, C = 2 batches take the tiled kernel below.)
@@ -358,19 +387,26 @@ int launch_backward_c(uint32_t C, const float *grad, const float *in, const int3
 
 }  // namespace occ
 
-OCC_API int occnerf_grid_encode_forward(const float *inputs, const float *embeddings,
-                                        const int32_t *offsets, float *outputs, uint32_t B,
-                                        uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                                        float *dy_dx, uint32_t gridtype, int align_corners,
-                                        uint32_t interp, void *stream) {
+static int grid_forward_impl(const float *inputs, const float *embeddings, const int32_t *offsets, const int32_t *h_off,
+                             float *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             float *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, void *stream) {
     using namespace occ;
     if (B == 0) return 0;
     OCC_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null tensor");
     OCC_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward: L=%u unsupported (1..%d)", L, kMaxLevels);
-    if (B == 0) return 0;
     const GridLevels lv = make_grid_levels(L, S, H);
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
+    if (h_off && D == 4 && C == 2 && gridtype == 0 && !ac && interp == 0 && !dy_dx && B <= (1u << 28)) {
+        uint32_t sizes[kMaxLevels] = {0};
+        for (uint32_t l = 0; l < L; l++) sizes[l] = (uint32_t)(h_off[l + 1] - h_off[l]);
+        const GridModes4 gm = make_grid_modes_d4(L, lv, sizes);
+        const uint32_t threads = B * 8;
+        hipLaunchKernelGGL(grid_forward_d4c2_kernel, dim3((threads + 255) / 256), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(inputs), reinterpret_cast<const float2 *>(embeddings), offsets,
+                           reinterpret_cast<float2 *>(outputs), B, L, lv, gm);
+        return check_launch("grid_encode_forward");
+    }
     switch (D) {
         case 2: return launch_forward_c<2>(C, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st);
         case 3: return launch_forward_c<3>(C, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st);
@@ -378,6 +414,24 @@ OCC_API int occnerf_grid_encode_forward(const float *inputs, const float *embedd
         case 5: return launch_forward_c<5>(C, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st);
         default: set_error("GridEncoding: D must be 2, 3, 4, or 5."); return 1;
     }
+}
+
+OCC_API int occnerf_grid_encode_forward(const float *inputs, const float *embeddings,
+                                        const int32_t *offsets, float *outputs, uint32_t B,
+                                        uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        float *dy_dx, uint32_t gridtype, int align_corners,
+                                        uint32_t interp, void *stream) {
+    return grid_forward_impl(inputs, embeddings, offsets, nullptr, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
+                             interp, stream);
+}
+
+OCC_API int occnerf_grid_encode_forward_h(const float *inputs, const float *embeddings, const int32_t *offsets,
+                                          const int32_t *h_offsets, float *outputs, uint32_t B, uint32_t D, uint32_t C,
+                                          uint32_t L, float S, uint32_t H, float *dy_dx, uint32_t gridtype,
+                                          int align_corners, uint32_t interp, void *stream) {
+    OCC_REQUIRE(h_offsets, "grid_encode_forward_h: null host offsets");
+    return grid_forward_impl(inputs, embeddings, offsets, h_offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
+                             align_corners, interp, stream);
 }
 
 static int grid_backward_impl(const float *grad, const float *inputs, const int32_t *offsets, const int32_t *h_off,

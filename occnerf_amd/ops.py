@@ -106,14 +106,24 @@ def _ptr_table(tensors, name):
 
 
 # ------------------------------------------------------------------ grid encoder (section 1)
+def _fp32_embeddings(embeddings, what):
+    """gridencoder.cu:467 dispatches on embeddings.scalar_type() over float / double / half (grid.py:42-45 feeds half
+    embeddings under autocast).  This build computes the encoder in fp32 only -- the dtype the rendering path uses and
+    the parity gate is stated in; other dtypes are refused by name instead of being silently converted."""
+    if torch.is_tensor(embeddings) and embeddings.dtype != torch.float32:
+        raise RuntimeError(f'{what}: embeddings are {embeddings.dtype}; this build implements the float32 dispatch case of '
+                           f'gridencoder.cu:467 only (float16 / float64 embeddings are not supported: cast with .float())')
+
+
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H, dy_dx=None,
                         gridtype=0, align_corners=False, interp=0):
     """Same positional signature as the reference's `_gridencoder.grid_encode_forward`
     (bindings.cpp:6); writes `outputs[L,B,C]` (and `dy_dx`) in place."""
+    _fp32_embeddings(embeddings, 'grid_encode_forward')
     with _guard(inputs):
-        rc = _lib.lib().occnerf_grid_encode_forward(
+        rc = _lib.lib().occnerf_grid_encode_forward_h(
             _chk(inputs, torch.float32, 'inputs'), _chk(embeddings, torch.float32, 'embeddings'),
-            _chk(offsets, torch.int32, 'offsets'), _chk(outputs, torch.float32, 'outputs'),
+            _chk(offsets, torch.int32, 'offsets'), _host_offsets(offsets), _chk(outputs, torch.float32, 'outputs'),
             int(B), int(D), int(Cc), int(L), float(S), int(H), _opt(dy_dx, torch.float32, 'dy_dx'),
             int(gridtype), int(bool(align_corners)), int(interp), _stream(inputs))
     _lib.check(rc, 'grid_encode_forward')
@@ -122,6 +132,7 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H,
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H,
                          dy_dx=None, grad_inputs=None, gridtype=0, align_corners=False, interp=0):
     """`_gridencoder.grid_encode_backward` (bindings.cpp:7)."""
+    _fp32_embeddings(embeddings, 'grid_encode_backward')
     with _guard(inputs):
         rc = _lib.lib().occnerf_grid_encode_backward_h(
             _chk(grad, torch.float32, 'grad'), _chk(inputs, torch.float32, 'inputs'),

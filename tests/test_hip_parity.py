@@ -89,6 +89,46 @@ def test_ops_refuse_cpu_tensors(ops):
         ops.grad_total_variation(None, None, None, None, 1e-7, 1, 4, 2, 16, 0.5, 16)
 
 
+def test_operator_seam_dtype_errors(ops):
+    """gridencoder.cu:467 dispatches float / double / half; this build implements float only and says so by name."""
+    x = torch.rand(8, 4, device=DEV)
+    off = torch.tensor([0, 64], dtype=torch.int32, device=DEV)
+    for dt in (torch.float16, torch.float64):
+        with pytest.raises(RuntimeError, match=str(dt).replace('torch.', '')):
+            ops.grid_encode_forward(x, torch.zeros(64, 2, device=DEV, dtype=dt), off, torch.zeros(1, 8, 2, device=DEV), 8, 4,
+                                    2, 1, 1.0, 16)
+        with pytest.raises(RuntimeError, match=str(dt).replace('torch.', '')):
+            ops.grid_encode_backward(torch.zeros(1, 8, 2, device=DEV), x, torch.zeros(64, 2, device=DEV, dtype=dt), off,
+                                     torch.zeros(64, 2, device=DEV), 8, 4, 2, 1, 1.0, 16)
+
+
+def test_operator_forward_d4c2_equals_reference_shaped_kernel(ops):
+    """The 8-lanes-per-sample D = 4, C = 2 operator forward (host-side level modes) against the reference-shaped
+    thread-per-(sample, level) kernel reached through the reference's own signature: bit-identical, including rows
+    outside [0,1], exact cell corners and a ragged batch; both table layouts (dense + hashed, all-hashed)."""
+    from occnerf_amd import _lib
+    from occnerf_amd.gridencoder import GridEncoder
+    for bound, B in ((1.4, 70001), (0.3, 4097)):
+        enc = GridEncoder(input_dim=4, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                          desired_resolution=2048 * bound).to(DEV)
+        enc.embeddings.data.uniform_(-1.0, 1.0)
+        g = torch.Generator(device='cpu').manual_seed(B)
+        x = torch.rand(B, 4, generator=g)
+        x[:7] = torch.tensor([[0, 0, 0, 0], [1, 1, 1, 1], [0.5, 0.25, 0.125, 1.0], [-1e-7, 0.5, 0.5, 0.5],
+                              [0.5, 1.0000001, 0.5, 0.5], [1.0, 0.0, 1.0, 0.0], [0.999999, 0.999999, 0.999999, 0.999999]])
+        x = x.to(DEV)
+        L, S, H = 16, enc.log2_per_level_scale, enc.base_resolution
+        fast = torch.full((L, B, 2), 7.0, device=DEV)
+        ops.grid_encode_forward(x, enc.embeddings.detach(), enc.offsets, fast, B, 4, 2, L, S, H)
+        slow = torch.full((L, B, 2), -7.0, device=DEV)
+        rc = _lib.lib().occnerf_grid_encode_forward(x.data_ptr(), enc.embeddings.data_ptr(), enc.offsets.data_ptr(),
+                                                    slow.data_ptr(), B, 4, 2, L, float(S), int(H), None, 0, 0, 0,
+                                                    torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        same(fast.cpu().numpy(), slow.cpu().numpy(), f'operator forward, bound {bound}')
+        assert float(fast[:, 3].abs().max()) == 0.0 and float(fast[:, 4].abs().max()) == 0.0      # out-of-range rows
+
+
 # ----------------------------------------------------------------------------- a14 / a19
 def test_grid_encode_forward_bit_exact(case, ops, oracle):
     g, ctx, _ = case
