@@ -301,10 +301,12 @@ int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const float *pa
 
 /* Alpha compositing, network.py:320-348.  raw[n,S,5], mask[n*S], z_vals[n,S],
  * rays[n,8] (direction at floats 3..5), h_bgcolor[3] host, 0..255.
- * Outputs rgb[n,3], acc[n], depth[n]; weights[n,S] and term[n] (argmax alpha) optional. */
+ * Outputs rgb[n,3], acc[n], depth[n]; weights[n,S] and term[n] (argmax alpha) optional.
+ * out_rows[n] (optional): ray r's rgb / acc / depth / term go to row out_rows[r] (the renderer walks the rays in
+ * Morton order and hands the results back in the caller's order without a separate gather). */
 int occnerf_composite(const float *raw, const float *mask, const float *z_vals, const float *rays,
                       const float *h_bgcolor, int64_t n, int32_t S, float *rgb, float *acc,
-                      float *depth, float *weights, int32_t *term, void *stream);
+                      float *depth, float *weights, int32_t *term, const int64_t *out_rows, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * 3. Training step (BASELINE configs[4]).  The reference
@@ -363,6 +365,20 @@ int occnerf_warp_backward(const float *rays, int64_t n, int32_t S, const float *
  * (softmax) and var[N] (unbiased variance of the normalised counts). */
 int occnerf_agg_weights(const float *counter, const int32_t *knn, int64_t N, int32_t K, float *atts, float *var,
                         void *stream);
+
+/* Per-frame preamble.
+ * occnerf_pose_motion_bases: pose refiner + motion bases in one launch.  h_W/h_b: HOST arrays of the 5 device weight /
+ *   bias pointers of BodyPoseRefiner.block_mlps.{0,2,4,6,8} (69 -> 256 x4 -> 69; mlp_delta_body_pose.py:35-41); refine = 0
+ *   skips the refiner (iter_val < pose_decoder.kick_in_iter, network.py:558).  posevec[69], dst_Rs[24,3,3], dst_Ts[24,3],
+ *   cnl_gtfms[24,4,4] -> Rs[24,3,3], Ts[24,3] (network_util.py:98-124,166-200; network.py:535-539).
+ * occnerf_prior_softmax: vol[C,V] = softmax over C of decoded[C,V] + log(prior[C,V]) (deconv_vol_decoder.py:31-33).
+ * occnerf_pack_rays: rays[2,R,3], near[R], far[R] -> rays8[R,8] = (o, d, near, far) of ray order[r] (order NULL: identity). */
+int occnerf_pose_motion_bases(const float *const *h_W, const float *const *h_b, const float *posevec, int32_t refine,
+                              const float *dst_Rs, const float *dst_Ts, const float *cnl_gtfms, float *Rs, float *Ts,
+                              void *stream);
+int occnerf_prior_softmax(const float *decoded, const float *prior, int32_t C, int64_t V, float *vol, void *stream);
+int occnerf_pack_rays(const float *rays, const float *near, const float *far, const int64_t *order, int64_t R, float *rays8,
+                      void *stream);
 
 /* Image assembly after the renderer, run.py:46-63 (unpack_to_image) + image_util.py:19-20 (to_8b_image) in one kernel:
  * out_rgb[H*W*3] = uint8(255 * clip(x, 0, 1)) of the ray's colour where a ray exists, of h_bgcolor01[3] (HOST,

@@ -60,7 +60,7 @@ SIGNATURES = {
     'occnerf_canonical_mlp_packed_bf16_bytes': (_i64, []),
     'occnerf_canonical_mlp_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_canonical_mlp_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp]),
-    'occnerf_composite': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_composite': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_linear_pack': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'occnerf_linear_forward': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32,
                                           _i32, _vp, _i32, _i64, _i64, _i32, _i32, _vp]),
@@ -71,6 +71,9 @@ SIGNATURES = {
     'occnerf_warp_backward_slices': (_i32, [_i64]),
     'occnerf_warp_backward': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_agg_weights': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    'occnerf_pose_motion_bases': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_prior_softmax': (C.c_int, [_vp, _vp, _i32, _i64, _vp, _vp]),
+    'occnerf_pack_rays': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'occnerf_assemble_image': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     'occnerf_convt3d_col2im': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'occnerf_convt3d_im2col': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),

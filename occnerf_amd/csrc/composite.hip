@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void composite_kernel(
     const float *__restrict__ raw, const float *__restrict__ mask, const float *__restrict__ z_vals,
     const float *__restrict__ rays, CompositeParams prm, int64_t n, int S, float *__restrict__ rgb_map,
     float *__restrict__ acc_map, float *__restrict__ depth_map, float *__restrict__ weights,
-    int32_t *__restrict__ term) {
+    int32_t *__restrict__ term, const int64_t *__restrict__ out_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -102,12 +102,13 @@ __global__ __launch_bounds__(256) void composite_kernel(
         }
         if (lane == 0) {
             const float rem = 1.0f - sa;                              // :346
-            rgb_map[r * 3 + 0] = sr + rem * prm.bg[0] / 255.0f;
-            rgb_map[r * 3 + 1] = sg + rem * prm.bg[1] / 255.0f;
-            rgb_map[r * 3 + 2] = sb + rem * prm.bg[2] / 255.0f;
-            acc_map[r] = sa;
-            depth_map[r] = sd;
-            if (term) term[r] = best_s;
+            const int64_t o = out_rows ? out_rows[r] : r;             // ray r of the (Morton-ordered) batch is the caller's ray o
+            rgb_map[o * 3 + 0] = sr + rem * prm.bg[0] / 255.0f;
+            rgb_map[o * 3 + 1] = sg + rem * prm.bg[1] / 255.0f;
+            rgb_map[o * 3 + 2] = sb + rem * prm.bg[2] / 255.0f;
+            acc_map[o] = sa;
+            depth_map[o] = sd;
+            if (term) term[o] = best_s;
         }
     }
 }
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void composite_kernel(
 OCC_API int occnerf_composite(const float *raw, const float *mask, const float *z_vals,
                               const float *rays, const float *h_bgcolor, int64_t n, int32_t S,
                               float *rgb, float *acc, float *depth, float *weights, int32_t *term,
-                              void *stream) {
+                              const int64_t *out_rows, void *stream) {
     using namespace occ;
     if (n <= 0) return 0;
     OCC_REQUIRE(raw && mask && z_vals && rays && h_bgcolor && rgb && acc && depth, "composite: null argument");
@@ -128,6 +129,6 @@ OCC_API int occnerf_composite(const float *raw, const float *mask, const float *
     int64_t blocks = (n + 3) / 4;                   // 4 waves (rays) per 256-thread block
     if (blocks > (int64_t)kNumCU * 32) blocks = (int64_t)kNumCU * 32;
     hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), raw, mask,
-                       z_vals, rays, prm, n, S, rgb, acc, depth, weights, term);
+                       z_vals, rays, prm, n, S, rgb, acc, depth, weights, term, out_rows);
     return check_launch("composite");
 }

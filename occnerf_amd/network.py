@@ -73,6 +73,7 @@ class Network(nn.Module):
             mlp_depth=cfg.pose_decoder.mlp_depth, total_bones=cfg.total_bones)
         self._ctx = None           # device-side constants of the sample pipeline
         self._ray_orders = {}      # ray_order_key -> (Morton permutation, its inverse)
+        self._wconst = None        # decoded volume logits + per-point table (functions of the weights only)
         self._packed = None        # MFMA-ordered MLP weights (eval: cached)
 
     # ------------------------------------------------------------------ model set-up
@@ -107,7 +108,7 @@ class Network(nn.Module):
         self.cnl_mlp = _Replica(CanonicalMLP(
             mlp_depth=cfg.canonical_mlp.mlp_depth, mlp_width=cfg.canonical_mlp.mlp_width,
             input_ch=63, skips=[], bound=self.bound, detailed_bound=self.detailed_bound))
-        self._ctx = self._packed = None
+        self._ctx = self._packed = self._wconst = None
 
     def deploy_mlps_to_secondary_gpus(self):
         return self          # single device per process; rays are sharded across processes
@@ -119,7 +120,7 @@ class Network(nn.Module):
     def invalidate_cache(self):
         """Drop the device-side constants and packed weights (load_state_dict and .to() do; in-place weight updates
         are noticed by themselves through the parameters' version counters)."""
-        self._ctx = self._packed = None
+        self._ctx = self._packed = self._wconst = None
         self._ray_orders = {}
 
     def load_state_dict(self, *a, **k):
@@ -190,6 +191,23 @@ class Network(nn.Module):
         }
         return self._packed
 
+    def _weight_constants(self):
+        """Everything of the per-frame preamble that is a function of the weights alone, cached per weight version:
+        the decoded motion-weight logits (deconv_vol_decoder.py:25-31: the decoder's input is the constant embedding, only
+        `log prior` changes from frame to frame) and the per-point feature table (network.py:263-284 +
+        occnerf_mlp.py:171-175, which the reference recomputes in every sample chunk)."""
+        dec_mod = self.mweight_vol_decoder
+        enc = self.cnl_mlp.module.encoder
+        srcs = list(dec_mod.parameters()) + [self.point_dist, self.point_base, enc.embeddings]
+        key = tuple((t.data_ptr(), t._version) for t in srcs)
+        if self._wconst is not None and self._wconst['key'] == key:
+            return self._wconst
+        with torch.no_grad():
+            dec = dec_mod.decoder.forward_gemm(dec_mod.const_embedding[None])[0].contiguous()
+            table = self._point_stage(self._context())
+        self._wconst = {'key': key, 'dec': dec, 'table': table}
+        return self._wconst
+
     def _point_stage(self, ctx):
         """network.py:263-284 + occnerf_mlp.py:171-175, once per frame."""
         enc = self.cnl_mlp.module.encoder
@@ -204,7 +222,9 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ sample pipeline
     def _render_rays(self, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann,
-                     table, t_rand=None):
+                     table, t_rand=None, out=None, out_rows=None):
+        """out: (rgb[R,3], alpha[R], depth[R]) of the whole frame; this pass's rays land in rows out_rows (their index
+        in the caller's order) or, without a permutation, in the slice the caller passes."""
         cfg, ctx = self.cfg, self._context()
         S = int(cfg.N_samples)
         enc = self.cnl_mlp.module.encoder
@@ -234,8 +254,7 @@ class Network(nn.Module):
             ops.canonical_mlp(mlp_in, pk['cnl'], raw_c, count=count)
             del mlp_in
             raw = ops.scatter_raw(raw_c, rows, count, torch.zeros(N, 5, device=xyz.device))
-            rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
-            return rgb, acc, depth
+            return ops.composite(raw, mask, z, rays8, bgcolor, out=out, out_rows=out_rows)[:3]
 
         # split-bf16 kernels (opt-in) take the list through the host: one nonzero = one sync
         rows = None
@@ -244,8 +263,7 @@ class Network(nn.Module):
             rows = None if rows64.numel() == N else rows64.int()
         if rows is not None and rows.numel() == 0:
             raw = torch.zeros(N, 5, device=xyz.device)
-            rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
-            return rgb, acc, depth
+            return ops.composite(raw, mask, z, rays8, bgcolor, out=out, out_rows=out_rows)[:3]
 
         def nonrigid(x):
             if pk['nr_bf16'] is not None:
@@ -278,8 +296,7 @@ class Network(nn.Module):
         else:
             raw = torch.zeros(N, 5, device=xyz.device)
             raw[rows64] = raw_c
-        rgb, acc, depth, _, _ = ops.composite(raw, mask, z, rays8, bgcolor)
-        return rgb, acc, depth
+        return ops.composite(raw, mask, z, rays8, bgcolor, out=out, out_rows=out_rows)[:3]
 
     @staticmethod
     def _ray_patch_order(rays_d):
@@ -336,77 +353,93 @@ class Network(nn.Module):
             return {'rgb': z.reshape(shape + [3]), 'alpha': z.reshape(shape), 'depth': z.reshape(shape),
                     'comp_loss': torch.zeros(0 if self.training else 1, device=dev)}
 
-        with torch.set_grad_enabled(want_grad):
-            # ---- per frame, torch (network.py:557-596) ----
-            if iter_val >= cfg.pose_decoder.get('kick_in_iter', 0):
-                refined = self.pose_decoder(dst_posevec)['Rs']
-                tb = cfg.total_bones - 1
-                no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3),
-                                       refined.reshape(-1, 3, 3)).reshape(-1, tb, 3, 3)
-                dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
-            nr = cfg.non_rigid_motion_mlp
-            hann = hann_window_weights(nr.multires, iter_val, nr.kick_in_iter, nr.full_band_iter)
-            cond = dst_posevec if iter_val >= nr.kick_in_iter else torch.zeros_like(dst_posevec)
-            Rs, Ts = self.motion_basis_computer(dst_Rs, dst_Ts, cnl_gtfms)
-            vol = self.mweight_vol_decoder(motion_weights_priors=motion_weights_priors)[0]
+        nr = cfg.non_rigid_motion_mlp
+        hann = hann_window_weights(nr.multires, iter_val, nr.kick_in_iter, nr.full_band_iter)       # host
+        refine = iter_val >= cfg.pose_decoder.get('kick_in_iter', 0)
+        bbox_min = self._host3(kwargs['cnl_bbox_min_xyz'])
+        bbox_scale = self._host3(kwargs['cnl_bbox_scale_xyz'])
+        bgcolor = self._host3(kwargs['bgcolor'])
+        S = int(cfg.N_samples)
+        rays_o, rays_d = rays
 
-            rays_o, rays_d = rays
-            rays8 = torch.cat([rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float(),
-                               near.reshape(-1, 1).float(), far.reshape(-1, 1).float()], -1)
-            # Morton order of the rays (kNN tiles, gather locality).  It depends on the camera only: a caller that
-            # renders many frames from one camera (movement sequences, the benchmark) names it with
-            # ray_order_key=<hashable> and the permutation (an argsort of R keys) is computed once.
-            order = None
-            if cfg.get('ray_patch_order', True):
-                key = kwargs.get('ray_order_key')
-                hit = self._ray_orders.get(key) if key is not None else None
-                if hit is not None and hit[0].numel() == rays8.shape[0] and hit[0].device == rays8.device:
-                    order, inv_cached = hit
-                else:
-                    order = self._ray_patch_order(rays8[:, 3:6])
-                    inv_cached = None
-                    if key is not None:
-                        inv_cached = torch.empty_like(order)
-                        inv_cached[order] = torch.arange(order.numel(), device=order.device)
-                        if len(self._ray_orders) >= 8:
-                            self._ray_orders.clear()
-                        self._ray_orders[key] = (order, inv_cached)
-            rays8 = (rays8[order] if order is not None else rays8).contiguous()
-            S = int(cfg.N_samples)
-            bbox_min = self._host3(kwargs['cnl_bbox_min_xyz'])
-            bbox_scale = self._host3(kwargs['cnl_bbox_scale_xyz'])
-            bgcolor = self._host3(kwargs['bgcolor'])
-            outs = []
-            if not fused:
-                # ---- differentiable path: HIP forward + HIP backward per stage (train_path.py) ----
-                from . import train_path
+        def morton_order(dirs):
+            """Morton order of the rays (kNN tiles, gather locality).  It depends on the camera only: a caller that
+            renders many frames from one camera (movement sequences, the benchmark) names it with
+            ray_order_key=<hashable> and the permutation (an argsort of R keys) is computed once."""
+            if not cfg.get('ray_patch_order', True):
+                return None
+            key = kwargs.get('ray_order_key')
+            hit = self._ray_orders.get(key) if key is not None else None
+            if hit is not None and hit.numel() == R and hit.device == dirs.device:
+                return hit
+            order = self._ray_patch_order(dirs)
+            if key is not None:
+                if len(self._ray_orders) >= 8:
+                    self._ray_orders.clear()
+                self._ray_orders[key] = order
+            return order
+
+        if fused:
+            # ---- render: 3 launches of per-frame preamble (csrc/preamble.hip), then the sample pipeline ----
+            with torch.no_grad():
+                wc = self._weight_constants()
+                f32 = lambda t: t.detach().float().contiguous()          # noqa: E731
+                Rs, Ts = ops.pose_motion_bases(self.pose_decoder, f32(dst_posevec).reshape(-1), refine, f32(dst_Rs[0]),
+                                               f32(dst_Ts[0]), f32(cnl_gtfms[0]))
+                vol = ops.prior_softmax(wc['dec'], f32(motion_weights_priors[0]))
+                cond = f32(dst_posevec).reshape(-1) if iter_val >= nr.kick_in_iter else \
+                    torch.zeros(dst_posevec.numel(), device=dev)
+                rays_f = f32(torch.stack([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)]) if not torch.is_tensor(rays) else
+                             rays.reshape(2, -1, 3))
+                order = morton_order(rays_f[1])
+                rays8 = ops.pack_rays(rays_f, f32(near).reshape(-1), f32(far).reshape(-1), order)
+                out = (torch.empty(R, 3, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev))
+                # all rays of the frame in as few passes as memory allows
+                rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 26)) // S)
+                for i in range(0, R, rays_per_pass):
+                    n = min(rays_per_pass, R - i)
+                    if order is not None:
+                        self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
+                                          wc['table'], out=out, out_rows=order[i:i + n])
+                    else:
+                        self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
+                                          wc['table'], out=tuple(t[i:i + n] for t in out))
+                rgb, acc, depth = out
+                comp_loss = torch.zeros(1, device=dev)
+        else:
+            # ---- differentiable path: per-frame modules in torch (gradients to the pose refiner and the volume
+            # decoder), then HIP forward + HIP backward per stage (train_path.py) ----
+            from . import train_path
+            with torch.set_grad_enabled(want_grad):
+                if refine:                                                       # network.py:557-596
+                    refined = self.pose_decoder(dst_posevec)['Rs']
+                    tb = cfg.total_bones - 1
+                    no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3),
+                                           refined.reshape(-1, 3, 3)).reshape(-1, tb, 3, 3)
+                    dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
+                cond = dst_posevec if iter_val >= nr.kick_in_iter else torch.zeros_like(dst_posevec)
+                Rs, Ts = self.motion_basis_computer(dst_Rs, dst_Ts, cnl_gtfms)
+                vol = self.mweight_vol_decoder(motion_weights_priors=motion_weights_priors)[0]
+                rays8 = torch.cat([rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float(),
+                                   near.reshape(-1, 1).float(), far.reshape(-1, 1).float()], -1)
+                order = morton_order(rays8[:, 3:6])
+                rays8 = (rays8[order] if order is not None else rays8).contiguous()
                 t_rand = kwargs.get('t_rand')            # optional injected jitter [R,S] (tests)
                 if t_rand is not None and order is not None:
                     t_rand = t_rand[order]
+                outs = []
                 for i in range(0, rays8.shape[0], int(cfg.chunk)):
                     outs.append(train_path.render_rays_autograd(
                         self, rays8[i:i + cfg.chunk], Rs[0], Ts[0], vol, bbox_min, bbox_scale, bgcolor, cond.float(),
                         hann.tolist(), None if t_rand is None else t_rand[i:i + cfg.chunk]))
-            else:
-                table = self._point_stage(self._context())
-                # ---- per sample, HIP; all rays of the frame in as few passes as memory allows ----
-                rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 26)) // S)
-                for i in range(0, rays8.shape[0], rays_per_pass):
-                    outs.append(self._render_rays(
-                        rays8[i:i + rays_per_pass], Rs[0].contiguous(), Ts[0].contiguous(),
-                        vol.contiguous(), bbox_min, bbox_scale, bgcolor,
-                        cond.reshape(-1).float().contiguous(), hann.tolist(), table)
-                        + (torch.zeros(1, 1, device=dev),))
-            rgb, acc, depth, comp_loss = (torch.cat(t, 0) if len(outs) > 1 else outs[0][j]
-                                          for j, t in enumerate(zip(*outs)))
-            if order is not None:            # back to the caller's ray order
-                inv = inv_cached
-                if inv is None:
+                rgb, acc, depth, comp_loss = (torch.cat(t, 0) if len(outs) > 1 else outs[0][j]
+                                              for j, t in enumerate(zip(*outs)))
+                if order is not None:            # back to the caller's ray order
                     inv = torch.empty_like(order)
                     inv[order] = torch.arange(order.numel(), device=order.device)
-                rgb, acc, depth = rgb[inv], acc[inv], depth[inv]
-                if comp_loss.shape[0] == order.numel():
-                    comp_loss = comp_loss[inv]
+                    rgb, acc, depth = rgb[inv], acc[inv], depth[inv]
+                    if comp_loss.shape[0] == order.numel():
+                        comp_loss = comp_loss[inv]
         return {'rgb': rgb.reshape(shape + [3]), 'alpha': acc.reshape(shape),
                 'depth': depth.reshape(shape),
                 'comp_loss': comp_loss.reshape(-1)}

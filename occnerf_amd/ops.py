@@ -451,12 +451,19 @@ def canonical_mlp_bf16x3(mlp_in, packed, packed_bf16, raw, variant=0):
     return raw
 
 
-def composite(raw, mask, z_vals, rays8, bgcolor, want_weights=False, want_term=False):
+def composite(raw, mask, z_vals, rays8, bgcolor, want_weights=False, want_term=False, out=None, out_rows=None):
+    """out_rows (int64[n], optional): results of ray r are written to row out_rows[r] of `out` = (rgb, acc, depth)
+    (caller-allocated, at least max(out_rows)+1 rows; without out_rows: exactly n rows)."""
     n, S = z_vals.shape
     dev = raw.device
-    rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
-    acc = torch.empty(n, device=dev, dtype=torch.float32)
-    dep = torch.empty(n, device=dev, dtype=torch.float32)
+    if out is None:
+        if out_rows is not None:
+            raise RuntimeError('composite: out_rows needs caller-allocated outputs')
+        out = (torch.empty(n, 3, device=dev, dtype=torch.float32), torch.empty(n, device=dev, dtype=torch.float32),
+               torch.empty(n, device=dev, dtype=torch.float32))
+    rgb, acc, dep = out
+    for t, nm in ((rgb, 'rgb'), (acc, 'acc'), (dep, 'depth')):
+        _chk(t, torch.float32, nm)
     w = torch.empty(n, S, device=dev, dtype=torch.float32) if want_weights else None
     tp = torch.empty(n, device=dev, dtype=torch.int32) if want_term else None
     _kbg, pbg = _host_f32(bgcolor, 3)
@@ -465,9 +472,53 @@ def composite(raw, mask, z_vals, rays8, bgcolor, want_weights=False, want_term=F
             _chk(raw, torch.float32, 'raw'), _chk(mask, torch.float32, 'mask'),
             _chk(z_vals, torch.float32, 'z_vals'), _chk(rays8, torch.float32, 'rays'), pbg, n, int(S),
             rgb.data_ptr(), acc.data_ptr(), dep.data_ptr(), None if w is None else w.data_ptr(),
-            None if tp is None else tp.data_ptr(), _stream(raw))
+            None if tp is None else tp.data_ptr(), _opt(out_rows, torch.int64, 'out_rows'), _stream(raw))
     _lib.check(rc, 'composite')
     return rgb, acc, dep, w, tp
+
+
+# ------------------------------------------------------------------ per-frame preamble
+def pose_motion_bases(pose_decoder, posevec, refine, dst_Rs, dst_Ts, cnl_gtfms):
+    """a2 + a3 in one launch -> Rs[24,3,3], Ts[24,3] (float32, on the device)."""
+    import torch.nn as nn
+    dev = dst_Rs.device
+    lin = [m for m in pose_decoder.block_mlps if isinstance(m, nn.Linear)]
+    if len(lin) != 5 or lin[0].in_features != 69 or lin[0].out_features != 256 or lin[4].out_features != 69:
+        raise RuntimeError('pose_motion_bases: the fused kernel is built for the 69 -> 256 x4 -> 69 refiner of occnerf.yaml')
+    Rs = torch.empty(24, 3, 3, device=dev, dtype=torch.float32)
+    Ts = torch.empty(24, 3, device=dev, dtype=torch.float32)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_pose_motion_bases(
+            _ptr_table([m.weight.detach() for m in lin], 'W'), _ptr_table([m.bias.detach() for m in lin], 'b'),
+            _chk(posevec, torch.float32, 'posevec'), int(bool(refine)), _chk(dst_Rs, torch.float32, 'dst_Rs'),
+            _chk(dst_Ts, torch.float32, 'dst_Ts'), _chk(cnl_gtfms, torch.float32, 'cnl_gtfms'), Rs.data_ptr(),
+            Ts.data_ptr(), _stream(dst_Rs))
+    _lib.check(rc, 'pose_motion_bases')
+    return Rs, Ts
+
+
+def prior_softmax(decoded, prior):
+    """softmax over channels of decoded[C,...] + log(prior[C,...]) -> vol, same shape."""
+    Cn = decoded.shape[0]
+    V = decoded.numel() // Cn
+    vol = torch.empty_like(decoded)
+    with _guard(decoded):
+        rc = _lib.lib().occnerf_prior_softmax(_chk(decoded, torch.float32, 'decoded'), _chk(prior, torch.float32, 'prior'),
+                                              int(Cn), int(V), vol.data_ptr(), _stream(decoded))
+    _lib.check(rc, 'prior_softmax')
+    return vol
+
+
+def pack_rays(rays, near, far, order=None):
+    """rays[2,R,3], near[R,1], far[R,1] -> rays8[R,8] in `order` (int64 permutation, optional)."""
+    R = rays.shape[1]
+    rays8 = torch.empty(R, 8, device=rays.device, dtype=torch.float32)
+    with _guard(rays):
+        rc = _lib.lib().occnerf_pack_rays(_chk(rays, torch.float32, 'rays'), _chk(near, torch.float32, 'near'),
+                                          _chk(far, torch.float32, 'far'), _opt(order, torch.int64, 'order'), R,
+                                          rays8.data_ptr(), _stream(rays))
+    _lib.check(rc, 'pack_rays')
+    return rays8
 
 
 # ------------------------------------------------------------------ training path: neighbour aggregation

@@ -97,6 +97,10 @@ class FusedAdam(torch.optim.Optimizer):
                 float(max_grad_norm) if max_grad_norm else 0.0, plan['scratch'].data_ptr(),
                 torch.cuda.current_stream(plan['device']).cuda_stream)
         _lib.check(rc, 'adam_step')
+        # the kernel wrote the parameters behind torch's back: move their version counters, which is what autograd's
+        # saved-tensor checks and the renderer's per-version caches (packed MLP weights, decoded volume, point table) key on
+        for _, p in items:
+            torch.autograd.graph.increment_version(p)
         return loss
 
     def grad_norm(self):

@@ -865,6 +865,67 @@ def test_per_frame_modules_on_gpu_against_reference(name):
         vol = net.mweight_vol_decoder(motion_weights_priors=d['motion_weights_priors'][None])[0]
         assert np.abs(vol[:, ::4, ::4, ::4].cpu().numpy() - g['mw.vol_slice']).max() <= 1e-5
         assert abs(float(vol.double().sum()) - float(g['mw.vol_sum'])) <= 1e-3 * abs(float(g['mw.vol_sum']))
+        # the render path's fused preamble (csrc/preamble.hip): one launch for a2 + a3, one for the softmax over
+        # (cached decoded logits + log prior) -- against the same reference outputs
+        from occnerf_amd import ops as o
+        Rs2, Ts2 = o.pose_motion_bases(net.pose_decoder, d['dst_posevec'].float().contiguous(), 'pose.Rs' in g,
+                                       d['dst_Rs'].float().contiguous(), d['dst_Ts'].float().contiguous(),
+                                       d['cnl_gtfms'].float().contiguous())
+        assert np.abs(Rs2.cpu().numpy() - g['mb.Rs'][0]).max() <= 2e-6
+        assert np.abs(Ts2.cpu().numpy() - g['mb.Ts'][0]).max() <= 2e-6
+        wc = net._weight_constants()
+        vol2 = o.prior_softmax(wc['dec'], d['motion_weights_priors'].float().contiguous())
+        assert np.abs(vol2[:, ::4, ::4, ::4].cpu().numpy() - g['mw.vol_slice']).max() <= 1e-5
+        assert float((vol2 - vol).abs().max()) <= 1e-6
+        assert net._weight_constants() is wc                      # cached: same weights, same object
+        net.point_dist.add_(1e-3)                                 # an in-place update, as an optimiser step does (under no_grad)
+        assert net._weight_constants() is not wc
+
+
+def test_caches_follow_in_place_weight_updates():
+    """A render after optimiser steps must use the updated weights (the packed MFMA weight streams, the decoded volume
+    logits and the per-point table are cached per weight version), whatever sequence of train()/eval() and
+    no_grad the caller goes through -- the reference trainer's progress renders do exactly this."""
+    from occnerf_amd import synth
+    from occnerf_amd.optim import FusedAdam
+    net, ctx = build_network(seed=0, amplify=True, S=32, non_rigid=True)
+    frame = synth.make_frame(img_size=48, pose72=synth.seeded_pose(1), orbit_frame=5)
+    data = frame_to_device(frame, DEV)
+
+    def render():
+        net.eval()
+        with torch.no_grad():
+            return net(**data, iter_val=1e7)['rgb'].clone()
+    a = render()
+    assert torch.equal(render(), a)
+    net.train()
+    with torch.no_grad():                                   # a render in train mode under no_grad in between
+        net(**data, iter_val=1e7)
+    opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-2)
+    out = net(**data, iter_val=1e7)
+    ((out['rgb'] - 0.3) ** 2).mean().backward()
+    opt.step(max_grad_norm=1.0)
+    b = render()
+    assert float((a - b).abs().max()) > 1e-4, 'the eval render after the step still shows the old weights'
+    fresh, _ = build_network(seed=0, amplify=True, S=32, non_rigid=True)
+    fresh.load_state_dict(net.state_dict(), strict=True)
+    fresh.eval()
+    with torch.no_grad():
+        c = fresh(**data, iter_val=1e7)['rgb']
+    assert torch.equal(b, c), 'a freshly built network with the same weights renders the same bits'
+
+
+def test_empty_ray_batch():
+    """A frame (or a rank's shard) without rays returns empty outputs instead of failing inside a kernel wrapper."""
+    from occnerf_amd import synth
+    net, ctx = build_network(seed=0, amplify=False, S=32, non_rigid=True)
+    frame = synth.make_frame(img_size=32, pose72=np.zeros(72, np.float32), orbit_frame=0)
+    for k in ('near', 'far'):
+        frame[k] = frame[k][:0]
+    frame['rays'] = frame['rays'][:, :0]
+    with torch.no_grad():
+        out = net(**frame_to_device(frame, DEV), iter_val=1e7)
+    assert out['rgb'].shape == (0, 3) and out['alpha'].shape == (0,) and out['depth'].shape == (0,)
 
 
 def _torchrun(script_args, nproc, timeout=900):

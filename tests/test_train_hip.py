@@ -406,6 +406,7 @@ def test_fused_adam_matches_torch(clip):
             grp['lr'] *= 0.9                               # what exp_decay.update_lr does between steps
     for a, b in zip(ref, mine):
         assert _rel(b.detach(), a.detach()) <= 2e-6
+    assert mine[0]._version >= 5 and mine[2]._version == 0      # updated in place 5 times / never touched
     sd_ref, sd_mine = o_ref.state_dict(), o_mine.state_dict()
     assert sorted(sd_ref['state']) == sorted(sd_mine['state'])
     for k in sd_ref['state']:
