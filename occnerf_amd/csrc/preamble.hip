@@ -21,25 +21,42 @@ struct PoseMlp {
     const float *b[5];
 };
 
-// y[j] = act(b[j] + sum_k W[j,k] x[k]) for j < out_dim: a wave owns a row at a time, lanes stride over k (coalesced
-// row reads), butterfly sum.  x, y in LDS.
+// y[j] = act(b[j] + sum_k W[j,k] x[k]) for j < out_dim.  The five layers are a dependent chain inside ONE workgroup, so
+// what matters is memory-level parallelism: each of the 16 waves takes 4 rows at a time and has all their loads (16-byte
+// pieces of contiguous weight rows, up to 16 per lane) in flight before the first FMA; butterfly sums; x, y in LDS.
 __device__ __forceinline__ void dense_layer(const float *__restrict__ W, const float *__restrict__ b, int in_dim, int out_dim,
                                             const float *x, float *y, bool relu) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int j = wave; j < out_dim; j += nw) {
-        float s = 0.0f;
-        for (int k = lane; k < in_dim; k += 64) s = __fmaf_rn(W[(size_t)j * in_dim + k], x[k], s);
+    for (int j0 = wave * 4; j0 < out_dim; j0 += nw * 4) {
+        float w[4][4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) {
-            s += b[j];
-            y[j] = relu ? fmaxf(s, 0.0f) : s;
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = lane + 64 * u, j = j0 + r;
+                w[r][u] = (k < in_dim && j < out_dim) ? W[(size_t)j * in_dim + k] : 0.0f;
+            }
+        }
+        float xs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) xs[u] = lane + 64 * u < in_dim ? x[lane + 64 * u] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; u++) s = __fmaf_rn(w[r][u], xs[u], s);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0 && j0 + r < out_dim) {
+                s += b[j0 + r];
+                y[j0 + r] = relu ? fmaxf(s, 0.0f) : s;
+            }
         }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void pose_motion_bases_kernel(PoseMlp mlp, const float *__restrict__ posevec, int refine,
+__global__ __launch_bounds__(1024) void pose_motion_bases_kernel(PoseMlp mlp, const float *__restrict__ posevec, int refine,
                                                                 const float *__restrict__ dst_Rs, const float *__restrict__ dst_Ts,
                                                                 const float *__restrict__ cnl_gtfms, float *__restrict__ Rs_out,
                                                                 float *__restrict__ Ts_out) {
@@ -172,7 +189,7 @@ OCC_API int occnerf_pose_motion_bases(const float *const *h_W, const float *cons
         mlp.W[l] = refine ? h_W[l] : nullptr;
         mlp.b[l] = refine ? h_b[l] : nullptr;
     }
-    hipLaunchKernelGGL(pose_motion_bases_kernel, dim3(1), dim3(256), 0, as_stream(stream), mlp, posevec, refine, dst_Rs, dst_Ts,
+    hipLaunchKernelGGL(pose_motion_bases_kernel, dim3(1), dim3(1024), 0, as_stream(stream), mlp, posevec, refine, dst_Rs, dst_Ts,
                        cnl_gtfms, Rs, Ts);
     return check_launch("pose_motion_bases");
 }

@@ -118,9 +118,28 @@ class ShardedRenderer:
         send = plan['send'][slot]
         if n_mine:
             local = dict(data)
-            local['rays'] = data['rays'][:, mine].to(self.device, non_blocking=True)
-            local['near'] = data['near'][mine].to(self.device, non_blocking=True)
-            local['far'] = data['far'][mine].to(self.device, non_blocking=True)
+            if n_mine == R:                                      # the whole frame is this rank's (one rank)
+                sub = (data['rays'], data['near'], data['far'])
+            elif data['rays'].is_cuda:
+                sub = (data['rays'][:, mine], data['near'][mine], data['far'][mine])
+            else:                                                # host frame: gather the shard into PINNED staging buffers, so
+                st = plan.setdefault('stage', [None, None])      # that the copies below really are asynchronous
+                if st[slot] is None:
+                    gpu = self.device.type == 'cuda'
+                    bufs = [torch.empty(2, n_mine, 3), torch.empty(n_mine, 1), torch.empty(n_mine, 1)]
+                    st[slot] = tuple(b.pin_memory() if gpu else b for b in bufs) + (torch.cuda.Event() if gpu else None,)
+                rs, ns, fs, ev = st[slot]
+                if ev is not None:
+                    ev.synchronize()                             # the copy issued from this slot two frames ago has left it
+                torch.index_select(data['rays'], 1, mine, out=rs)
+                torch.index_select(data['near'].reshape(-1, 1), 0, mine, out=ns)
+                torch.index_select(data['far'].reshape(-1, 1), 0, mine, out=fs)
+                sub = (rs, ns, fs)
+            local['rays'] = sub[0].to(self.device, non_blocking=True)
+            local['near'] = sub[1].to(self.device, non_blocking=True)
+            local['far'] = sub[2].to(self.device, non_blocking=True)
+            if not data['rays'].is_cuda and n_mine != R and plan['stage'][slot][3] is not None:
+                plan['stage'][slot][3].record(torch.cuda.current_stream(self.device))
             for k, v in data.items():
                 if k not in ('rays', 'near', 'far') and torch.is_tensor(v) and not v.is_cuda and v.numel() > 3:
                     local[k] = v.to(self.device, non_blocking=True)
