@@ -20,6 +20,8 @@
 // instructions each); support set 146 KB streamed through the scalar cache per wave.
 #include "common.h"
 
+#include <mutex>
+
 #include <cmath>
 #include <vector>
 
@@ -207,13 +209,18 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     const float *__restrict__ xyz, const float *__restrict__ mask /*nullable*/, int64_t n_rays, int S,
     const float4 *__restrict__ points, const float4 *__restrict__ centers,
     const int2 *__restrict__ ranges /*[nscale-1][ncl]*/, const float *__restrict__ radius /*[nscale-1][ncl]*/,
-    ClusteredScales sc, int32_t *__restrict__ knn_idxs) {
+    ClusteredScales sc, int32_t *__restrict__ knn_idxs, unsigned *__restrict__ ticket) {
     const int lane = threadIdx.x & 63;
     const int tiles_per_chunk = (S + 3) / 4;
     const int64_t n_tiles = ((n_rays + 63) / 64) * tiles_per_chunk;
-    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
+    // Tiles differ widely in cost (a tile of dead samples is skipped after its mask loads, a tile near the body
+    // visits many clusters), so the waves draw tiles from a counter instead of striding over them: with ~6 tiles per
+    // resident wave a static assignment left a third of the wave slots idle in the kernel's tail.
+    for (;;) {
+        unsigned t32 = 0;
+        if (lane == 0) t32 = atomicAdd(ticket, 1u);
+        const int64_t tile = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t32);
+        if (tile >= n_tiles) break;
         // lane = one of 64 neighbouring rays (the host orders rays in compact pixel patches),
         // its 4 queries = 4 consecutive samples of that ray
         const int64_t ray = (tile / tiles_per_chunk) * 64 + lane;
@@ -468,12 +475,26 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t
         sc.seed[l] = (l < nscale && h_seed_from_coarser) ? h_seed_from_coarser[l] : 0;
     }
     const int64_t tiles = ((n_rays + 63) / 64) * ((samples_per_ray + 3) / 4);
+    OCC_REQUIRE(tiles < (1ll << 31), "msknn_clustered: too many tiles for one launch");
     int64_t blocks = (tiles + 3) / 4;
-    if (blocks > (int64_t)kNumCU * 16) blocks = (int64_t)kNumCU * 16;
+    if (blocks > (int64_t)kNumCU * 3) blocks = (int64_t)kNumCU * 3;      // 12 resident waves per CU at this register count
+    // ticket counter of this launch: a slot of a small per-device ring, zeroed on the launch stream
+    static std::mutex mu;
+    static unsigned *ring[16] = {nullptr};
+    static unsigned next[16] = {0};
+    int dev = 0;
+    OCC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "msknn_clustered: device id");
+    unsigned *ticket;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ring[dev]) OCC_REQUIRE(hipMalloc(&ring[dev], 64 * sizeof(unsigned)) == hipSuccess, "msknn_clustered: hipMalloc");
+        ticket = ring[dev] + (next[dev]++ & 63);
+    }
+    OCC_REQUIRE(hipMemsetAsync(ticket, 0, sizeof(unsigned), as_stream(stream)) == hipSuccess, "msknn_clustered: memset");
     hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, mask,
                        n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points),
                        reinterpret_cast<const float4 *>(centers), reinterpret_cast<const int2 *>(cluster_ranges),
-                       cluster_radius, sc, knn_idxs);
+                       cluster_radius, sc, knn_idxs, ticket);
     return check_launch("msknn_clustered");
 }
 
