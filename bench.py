@@ -104,15 +104,11 @@ def timed_steps(renderer, frame_h, steps, warmup, rank, world, dev, order_key, h
             if prev is not None:
                 out = renderer.finish(prev)
                 if out is not None:
-                    host_out[:, :3].copy_(out['rgb'], non_blocking=True)
-                    host_out[:, 3].copy_(out['alpha'], non_blocking=True)
-                    host_out[:, 4].copy_(out['depth'], non_blocking=True)
+                    host_out.copy_(out['packed'], non_blocking=True)      # one contiguous [R,5] D2H into pinned memory
             prev = cur
         out = renderer.finish(prev)
         if out is not None:
-            host_out[:, :3].copy_(out['rgb'], non_blocking=True)
-            host_out[:, 3].copy_(out['alpha'], non_blocking=True)
-            host_out[:, 4].copy_(out['depth'], non_blocking=True)
+            host_out.copy_(out['packed'], non_blocking=True)
         if events is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record(stream)

@@ -163,7 +163,7 @@ class ShardedRenderer:
             if self.rank != 0:
                 return None
             full = plan['recv'][pending.slot].index_select(0, plan['unpermute'])
-        return {'rgb': full[:, :3], 'alpha': full[:, 3], 'depth': full[:, 4]}
+        return {'rgb': full[:, :3], 'alpha': full[:, 3], 'depth': full[:, 4], 'packed': full}     # packed: contiguous [R,5]
 
     def render_frames(self, frames, iter_val=1e7, **net_kwargs):
         """Generator over `frames`: frame t's gather overlaps frame t+1's kernels (one frame of lag)."""
