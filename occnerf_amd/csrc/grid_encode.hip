@@ -13,6 +13,8 @@
 // [L,B,C] output layout, so that concurrently running blocks work on the same level.
 #include "common.h"
 
+#include <vector>
+
 namespace occ {
 
 template <uint32_t D, uint32_t C>
@@ -230,6 +232,90 @@ struct TileJobs {
     GridModes4 modes;
 };
 
+// MODE (kGridDense / kGridHashPow2 / kGridGeneric) is a template parameter: with it as a run-time value hipcc replicated
+// the corner loop per mode and turned the 16 hit tests into 16 branches.
+template <uint32_t MODE>
+__device__ __forceinline__ void grid_backward_tile_scan(double *s_g, const float2 *__restrict__ g2,
+                                                        const float4 *__restrict__ inputs, uint32_t B, uint32_t tile,
+                                                        uint32_t size, float scale, uint32_t resolution) {
+    const uint32_t base = tile * kTileEntries;
+    // Four samples per trip keep 8 loads in flight per lane.
+    constexpr uint32_t U = 4;
+    for (uint32_t b0 = threadIdx.x; b0 < B; b0 += blockDim.x * U) {
+        float4 xv4[U];
+        float2 gv4[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t bb = b0 + u * blockDim.x < B ? b0 + u * blockDim.x : B - 1;
+            xv4[u] = inputs[bb];
+            gv4[u] = g2[bb];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const float2 gv = gv4[u];
+            const float x[4] = {xv4[u].x, xv4[u].y, xv4[u].z, xv4[u].w};
+            // rows outside [0,1] keep a zero gradient (gridencoder.cu:262-266); exact-zero gradient rows (samples the
+            // compositor masks out) add exact zeros
+            bool live = b0 + u * blockDim.x < B && !(gv.x == 0.0f && gv.y == 0.0f);
+            float f[4][2];
+            uint32_t pg[4], t[4][2];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                live = live && !(x[d] < 0.f || x[d] > 1.f);
+                float pos = __fmaf_rn(x[d], scale, 0.5f);
+                const float fl = floorf(pos);
+                pg[d] = (uint32_t)fl;
+                pos -= fl;
+                f[d][0] = __fsub_rn(1.f, pos);
+                f[d][1] = pos;
+            }
+            if (MODE == kGridDense) {
+                uint32_t stride = 1;
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    t[d][0] = pg[d] * stride;
+                    t[d][1] = t[d][0] + stride;
+                    stride *= resolution + 1;
+                }
+            } else {
+                constexpr uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    t[d][0] = pg[d] * primes[d];
+                    t[d][1] = t[d][0] + primes[d];
+                }
+            }
+            auto corner_index = [&](uint32_t c) -> uint32_t {
+                const uint32_t t0 = (c & 1) ? t[0][1] : t[0][0], t1 = (c & 2) ? t[1][1] : t[1][0];
+                const uint32_t t2 = (c & 4) ? t[2][1] : t[2][0], t3 = (c & 8) ? t[3][1] : t[3][0];
+                if (MODE == kGridDense) return t0 + t1 + t2 + t3;
+                if (MODE == kGridHashPow2) return (t0 ^ t1 ^ t2 ^ t3) & (size - 1);
+                const uint32_t pl[4] = {pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), pg[3] + ((c >> 3) & 1)};
+                return grid_index<4>(0, false, size, resolution, pl);
+            };
+            // Which of the 16 corners fall into this tile (1 in 64 on a hashed level).  An LDS atomic costs its cycles per
+            // wave-instruction however few lanes are active, and with one conditional pair per corner almost every one of
+            // the 32 instructions finds SOME lane with a hit: the hits are first collected as a per-lane bit mask (no
+            // branches) and then drained together -- max-over-lanes(hits) = 2-3 pairs per wave instead of 32.
+            uint32_t hits = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < 16; c++) hits |= (uint32_t)(corner_index(c) - base < kTileEntries) << c;
+            hits = live ? hits : 0u;
+            while (hits) {
+                const uint32_t c = (uint32_t)__builtin_ctz(hits);
+                hits &= hits - 1;
+                const uint32_t local = corner_index(c) - base;
+                // weight exactly as the scatter kernel forms it: ((1 * a0) * a1) * a2) * a3
+                const float w = __fmul_rn(__fmul_rn(__fmul_rn((c & 1) ? f[0][1] : f[0][0], (c & 2) ? f[1][1] : f[1][0]),
+                                                    (c & 4) ? f[2][1] : f[2][0]),
+                                          (c & 8) ? f[3][1] : f[3][0]);
+                atomicAdd(&s_g[local * 2], (double)__fmul_rn(w, gv.x));
+                atomicAdd(&s_g[local * 2 + 1], (double)__fmul_rn(w, gv.y));
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void grid_backward_tiled_d4c2_kernel(
     const float *__restrict__ grad, const float4 *__restrict__ inputs, const int32_t *__restrict__ offsets,
     float *__restrict__ grad_grid, uint32_t B, GridLevels lv, TileJobs jobs) {
@@ -246,85 +332,12 @@ __global__ __launch_bounds__(1024) void grid_backward_tiled_d4c2_kernel(
     const uint32_t resolution = lv.resolution[level];
     const uint32_t mode = jobs.modes.mode[level];
     const float2 *g2 = reinterpret_cast<const float2 *>(grad) + (size_t)level * B;
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
-        const float4 xv = inputs[b];
-        const float x[4] = {xv.x, xv.y, xv.z, xv.w};
-        bool in = true;
-        float f[4][2];
-        uint32_t pg[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            in = in && !(x[d] < 0.f || x[d] > 1.f);
-            float pos = __fmaf_rn(x[d], scale, 0.5f);
-            const float fl = floorf(pos);
-            pg[d] = (uint32_t)fl;
-            pos -= fl;
-            f[d][0] = __fsub_rn(1.f, pos);
-            f[d][1] = pos;
-        }
-        if (!in) continue;                       // gradient stays zero (gridencoder.cu:262-266)
-        uint32_t t[4][2];
-        if (mode == kGridDense) {
-            uint32_t stride = 1;
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                t[d][0] = pg[d] * stride;
-                t[d][1] = (pg[d] + 1) * stride;
-                stride *= resolution + 1;
-            }
-        } else {
-            constexpr uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                t[d][0] = pg[d] * primes[d];
-                t[d][1] = (pg[d] + 1) * primes[d];
-            }
-        }
-        const float2 gv = g2[b];
-        if (gv.x == 0.0f && gv.y == 0.0f) continue;          // adds exact zeros (e.g. samples the compositor masks out)
-        if (mode == kGridGeneric) {
-#pragma unroll
-            for (uint32_t idx = 0; idx < 16; idx++) {
-                const int b0 = idx & 1, b1 = (idx >> 1) & 1, b2 = (idx >> 2) & 1, b3 = (idx >> 3) & 1;
-                const uint32_t pl[4] = {pg[0] + b0, pg[1] + b1, pg[2] + b2, pg[3] + b3};
-                const uint32_t local = grid_index<4>(0, false, size, resolution, pl) - tile * kTileEntries;
-                if (local < kTileEntries) {
-                    const float w = __fmul_rn(__fmul_rn(__fmul_rn(f[0][b0], f[1][b1]), f[2][b2]), f[3][b3]);
-                    atomicAdd(&s_g[local * 2], (double)__fmul_rn(w, gv.x));
-                    atomicAdd(&s_g[local * 2 + 1], (double)__fmul_rn(w, gv.y));
-                }
-            }
-            continue;
-        }
-        // Which of the 16 corners fall into this tile (1 in 64 on a hashed level).  An LDS atomic costs its
-        // ~16 cycles per wave-instruction however few lanes are active, and with one conditional pair per corner
-        // almost every one of the 32 instructions finds SOME lane with a hit: the LDS port was the bound of this
-        // kernel.  So the hits are first collected as a per-lane bit mask and then drained together: the wave
-        // issues max-over-lanes(hits) pairs (2-3) instead of 32.
-        const bool dense = mode == kGridDense;
-        uint32_t hits = 0;
-#pragma unroll
-        for (uint32_t idx = 0; idx < 16; idx++) {
-            const int b0 = idx & 1, b1 = (idx >> 1) & 1, b2 = (idx >> 2) & 1, b3 = (idx >> 3) & 1;
-            const uint32_t index = dense ? t[0][b0] + t[1][b1] + t[2][b2] + t[3][b3]
-                                         : (t[0][b0] ^ t[1][b1] ^ t[2][b2] ^ t[3][b3]) & (size - 1);
-            if (index - tile * kTileEntries < kTileEntries) hits |= 1u << idx;
-        }
-        while (hits) {
-            const uint32_t c = (uint32_t)__builtin_ctz(hits);
-            hits &= hits - 1;
-            const uint32_t t0 = (c & 1) ? t[0][1] : t[0][0], t1 = (c & 2) ? t[1][1] : t[1][0];
-            const uint32_t t2 = (c & 4) ? t[2][1] : t[2][0], t3 = (c & 8) ? t[3][1] : t[3][0];
-            const uint32_t index = dense ? t0 + t1 + t2 + t3 : (t0 ^ t1 ^ t2 ^ t3) & (size - 1);
-            const uint32_t local = index - tile * kTileEntries;
-            // weight exactly as the scatter kernel forms it: ((1 * a0) * a1) * a2) * a3
-            const float w = __fmul_rn(__fmul_rn(__fmul_rn((c & 1) ? f[0][1] : f[0][0], (c & 2) ? f[1][1] : f[1][0]),
-                                                (c & 4) ? f[2][1] : f[2][0]),
-                                      (c & 8) ? f[3][1] : f[3][0]);
-            atomicAdd(&s_g[local * 2], (double)__fmul_rn(w, gv.x));
-            atomicAdd(&s_g[local * 2 + 1], (double)__fmul_rn(w, gv.y));
-        }
-    }
+    if (mode == kGridDense)
+        grid_backward_tile_scan<kGridDense>(s_g, g2, inputs, B, tile, size, scale, resolution);
+    else if (mode == kGridHashPow2)
+        grid_backward_tile_scan<kGridHashPow2>(s_g, g2, inputs, B, tile, size, scale, resolution);
+    else
+        grid_backward_tile_scan<kGridGeneric>(s_g, g2, inputs, B, tile, size, scale, resolution);
     __syncthreads();
     const uint32_t n_here = size - tile * kTileEntries < kTileEntries ? size - tile * kTileEntries : kTileEntries;
     float *dst = grad_grid + ((size_t)off0 + (size_t)tile * kTileEntries) * 2;
@@ -449,16 +462,32 @@ static int grid_backward_impl(const float *grad, const float *inputs, const int3
     const bool ac = align_corners != 0;
     if (h_off && D == 4 && C == 2 && gridtype == 0 && !ac && interp == 0 && B >= 32768) {
         // tiled, atomics-free path; the level sizes come from the caller's HOST copy of the offsets
+        // Job order.  Every tile-job of a level streams the same 19 MB (the samples' inputs + that level's gradient
+        // rows); counters showed the kernel waiting on exactly that stream (SQ_WAIT_ANY 48 % of wave time).  Workgroup b
+        // runs on XCD b % 8 (observed placement: used for speed only), so level l's jobs are queued on XCD l % 8: its tiles
+        // then run side by side behind ONE L2 and read the stream in step, instead of 8 tiles behind each of 8 L2s.
         TileJobs jobs;
         jobs.n = 0;
         uint32_t sizes[kMaxLevels] = {0};
-        bool fits = true;
+        std::vector<uint32_t> queue[8];
+        uint32_t total = 0;
         for (uint32_t l = 0; l < L; l++) {
             sizes[l] = (uint32_t)(h_off[l + 1] - h_off[l]);
             const uint32_t nt = (sizes[l] + kTileEntries - 1) / kTileEntries;
-            for (uint32_t t = 0; t < nt; t++) {
-                if (jobs.n >= 1024) { fits = false; break; }
-                jobs.level_tile[jobs.n++] = (l << 16) | t;
+            for (uint32_t t = 0; t < nt; t++) queue[l % 8].push_back((l << 16) | t);
+            total += nt;
+        }
+        const bool fits = total <= 1024;
+        if (fits) {
+            size_t head[8] = {0};
+            for (uint32_t b = 0; b < total; b++) {
+                uint32_t x = b % 8;
+                if (head[x] >= queue[x].size()) {              // this XCD's queue is empty: take from the fullest one
+                    size_t best = 0;
+                    for (uint32_t y = 0; y < 8; y++)
+                        if (queue[y].size() - head[y] > best) { best = queue[y].size() - head[y]; x = y; }
+                }
+                jobs.level_tile[jobs.n++] = queue[x][head[x]++];
             }
         }
         if (fits && jobs.n > 0) {
