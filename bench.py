@@ -185,13 +185,17 @@ def main():
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = int(os.environ.get('OCC_FORCE_DEVICE', os.environ.get('LOCAL_RANK', 0)))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    backend = os.environ.get('OCC_DIST_BACKEND', 'nccl')     # 'gloo' + OCC_FORCE_DEVICE=0: dry run of the N > 1 path on one GPU
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from occnerf_amd import ops, synth
     from occnerf_amd.parallel import ShardedRenderer
@@ -281,7 +285,7 @@ def main():
                        'rays_per_frame': R, 'samples_per_ray': SPP, 'image': [IMG, IMG],
                        'samples_evaluated_per_launch': float(np.mean(nsmp)),
                        'skip_empty_samples': bool(net.cfg.get('skip_empty_samples', True)),
-                       'world_size_formed': renderer.formed_world_size(),
+                       'world_size_formed': renderer.formed_world_size(), 'backend': backend if world > 1 else None,
                        'parallelism': f'one frame, rays sharded x{world} in 4096-ray chunks, async RCCL gather to rank 0 '
                                       'overlapped with the next frame'},
             'roofline': {'bound': 'mfma', 'kernel': 'occ::m16::canonical_mlp_lds_kernel (fp32 MFMA 16x16x4, LDS-staged weights)',

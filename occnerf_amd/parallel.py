@@ -65,11 +65,11 @@ def gather_rays(block, n_rays, dst=0, group=None):
 
 
 class _Pending:
-    """One frame in flight: the gather's work handle and the slot holding its buffers."""
-    __slots__ = ('work', 'slot', 'n_rays', 'local')
+    """One frame in flight: the gather's work handle, its plan (buffers) and the slot used."""
+    __slots__ = ('work', 'slot', 'n_rays', 'plan')
 
-    def __init__(self, work, slot, n_rays, local):
-        self.work, self.slot, self.n_rays, self.local = work, slot, n_rays, local
+    def __init__(self, work, slot, n_rays, plan):
+        self.work, self.slot, self.n_rays, self.plan = work, slot, n_rays, plan
 
 
 class ShardedRenderer:
@@ -80,7 +80,10 @@ class ShardedRenderer:
         self.net, self.device, self.group, self.chunk, self.channels = net, torch.device(device), group, int(chunk), channels
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() and not single else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
-        self._plan = None
+        # gloo has no gather on device tensors: with that backend (tests: several processes sharing one GPU) the blocks
+        # are exchanged through host buffers; with nccl (= RCCL) they stay on the device
+        self.host_exchange = self.world > 1 and self.device.type == 'cuda' and dist.get_backend(group) == 'gloo'
+        self._plans = {}          # rays per frame -> shard plan with its buffers (frames in flight keep theirs)
         self._turn = 0
 
     def formed_world_size(self):
@@ -88,14 +91,19 @@ class ShardedRenderer:
         return self.world
 
     def _get_plan(self, R):
-        if self._plan is not None and self._plan['R'] == R:
-            return self._plan
+        hit = self._plans.get(R)
+        if hit is not None:
+            return hit
         shards = [shard_indices(R, r, self.world, self.chunk) for r in range(self.world)]
         sizes = [int(s.numel()) for s in shards]
         width = max(max(sizes), 1)
         plan = {'R': R, 'mine_cpu': shards[self.rank], 'mine_dev': shards[self.rank].to(self.device), 'sizes': sizes,
                 'width': width,
                 'send': [torch.zeros(width, self.channels, device=self.device) for _ in range(2)]}
+        if self.host_exchange:
+            plan['send_host'] = [torch.zeros(width, self.channels).pin_memory() for _ in range(2)]
+            if self.rank == 0:
+                plan['recv_host'] = [torch.empty(self.world * width, self.channels).pin_memory() for _ in range(2)]
         if self.rank == 0 and self.world > 1:
             # position in the concatenated [world * width] receive buffer of every ray of the frame
             src = torch.empty(R, dtype=torch.long)
@@ -103,7 +111,9 @@ class ShardedRenderer:
                 src[s] = r * width + torch.arange(sizes[r])
             plan['unpermute'] = src.to(self.device)
             plan['recv'] = [torch.empty(self.world * width, self.channels, device=self.device) for _ in range(2)]
-        self._plan = plan
+        if len(self._plans) >= 4:                                 # a sequence's frames differ in ray count: keep a few plans
+            self._plans.pop(next(iter(self._plans)))
+        self._plans[R] = plan
         return plan
 
     def submit(self, data, iter_val=1e7, **net_kwargs):
@@ -148,20 +158,27 @@ class ShardedRenderer:
             send[:n_mine, 3] = out['alpha']
             send[:n_mine, 4] = out['depth']
         if self.world == 1:
-            return _Pending(None, slot, R, None)
-        recv = list(plan['recv'][slot].view(self.world, plan['width'], self.channels).unbind(0)) if self.rank == 0 else None
+            return _Pending(None, slot, R, plan)
+        if self.host_exchange:
+            send = plan['send_host'][slot].copy_(send)               # (synchronous: the gloo path is a test vehicle)
+            rbuf = plan['recv_host'][slot] if self.rank == 0 else None
+        else:
+            rbuf = plan['recv'][slot] if self.rank == 0 else None
+        recv = list(rbuf.view(self.world, plan['width'], self.channels).unbind(0)) if self.rank == 0 else None
         work = dist.gather(send, recv, dst=0, group=self.group, async_op=True)
-        return _Pending(work, slot, R, None)
+        return _Pending(work, slot, R, plan)
 
     def finish(self, pending):
         """Wait for a frame's gather; -> {'rgb','alpha','depth'} in the caller's ray order on rank 0, None elsewhere."""
-        plan = self._get_plan(pending.n_rays)
+        plan = pending.plan
         if self.world == 1:
             full = plan['send'][pending.slot][:pending.n_rays]
         else:
             pending.work.wait()
             if self.rank != 0:
                 return None
+            if self.host_exchange:
+                plan['recv'][pending.slot].copy_(plan['recv_host'][pending.slot], non_blocking=True)
             full = plan['recv'][pending.slot].index_select(0, plan['unpermute'])
         return {'rgb': full[:, :3], 'alpha': full[:, 3], 'depth': full[:, 4], 'packed': full}     # packed: contiguous [R,5]
 

@@ -101,7 +101,11 @@ def _gloo_worker(rank, world, port, n_rays, q):
     ok = check(out, data) if rank == 0 else out is None
     # pipelined: frame t's gather is waited for after frame t+1 has been submitted (two buffer slots, reused)
     from occnerf_amd.parallel import ShardedRenderer
-    frames = [{k: v * (1.0 + 0.25 * t) for k, v in data.items()} for t in range(5)]
+    frames = []
+    for t in range(5):                                    # frames of a sequence differ in ray count
+        keep = n_rays - 7 * t
+        frames.append({'rays': data['rays'][:, :keep] * (1.0 + 0.25 * t), 'near': data['near'][:keep] + t,
+                       'far': data['far'][:keep] * 2.0})
     r = ShardedRenderer(FakeNet(), 'cpu', chunk=96)
     assert r.formed_world_size() == world
     outs = list(r.render_frames(frames))

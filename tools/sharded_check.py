@@ -1,5 +1,7 @@
-"""Run under torchrun on >= 2 GPUs: one 256x256x64 frame rendered with its rays sharded over the ranks (RCCL gather,
-pipelined over 3 frames) must equal, bit for bit, the same frame rendered by rank 0 alone.  Prints one JSON line.
+"""Run under torchrun on >= 2 GPUs: three 256x256x64 frames rendered with their rays sharded over the ranks (RCCL gather,
+pipelined) must equal, bit for bit, the same frames rendered by rank 0 alone.  Prints one JSON line.
+With OCC_DIST_BACKEND=gloo OCC_FORCE_DEVICE=0 the ranks share one GPU and exchange through the host (RCCL refuses two
+ranks on one device): everything but the collective itself is then the production code path.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tools/sharded_check.py
 """
 import json
@@ -14,10 +16,15 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
+    local = int(os.environ.get('OCC_FORCE_DEVICE', local))        # experiment: several ranks on one GPU
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    backend = os.environ.get('OCC_DIST_BACKEND', 'nccl')             # 'gloo': several processes on one GPU, host exchange
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     from occnerf_amd import synth
     from occnerf_amd.parallel import ShardedRenderer
     from tests.gpu_util import build_network, FRAME_KEYS
@@ -35,7 +42,7 @@ def main():
                 for k in ('rgb', 'alpha', 'depth'):
                     ok = ok and torch.equal(a[k], b[k])
                     worst = max(worst, float((a[k] - b[k]).abs().max()))
-            print(json.dumps({'world_size_formed': dist.get_world_size(), 'frames': len(frames), 'bit_identical': bool(ok),
+            print(json.dumps({'world_size_formed': dist.get_world_size(), 'backend': backend, 'frames': len(frames), 'bit_identical': bool(ok),
                               'max_abs_diff': worst, 'rays': [int(f['rays'].shape[1]) for f in frames]}))
     dist.barrier()
     dist.destroy_process_group()
