@@ -72,12 +72,14 @@ int occnerf_grid_encode_forward_h(const float *inputs, const float *embeddings, 
 /* occnerf_grid_encode_backward with the level offsets also given as a HOST array h_offsets[L+1].  The
  * reference's signature above cannot know the level sizes without reading device memory, so it always runs
  * the atomic scatter (gridencoder.cu:248-340 as written); with the host copy, large D = 4, C = 2 hash batches
- * take the atomics-free path (workgroup-owned LDS tiles of the table, fp64 accumulators). */
+ * take the atomics-free path (workgroup-owned LDS tiles of the table, fp64 accumulators).  scratch (optional, device,
+ * scratch_bytes >= L * B * 8): room for the per-(level, sample) tile sets of the pre-pass that lets a tile-job hash only the
+ * samples that touch it; without it every tile-job re-hashes every sample (same results). */
 int occnerf_grid_encode_backward_h(const float *grad, const float *inputs, const float *embeddings,
                                    const int32_t *offsets, const int32_t *h_offsets, float *grad_embeddings,
                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                    const float *dy_dx, float *grad_inputs, uint32_t gridtype, int align_corners,
-                                   uint32_t interp, void *stream);
+                                   uint32_t interp, void *scratch, int64_t scratch_bytes, void *stream);
 
 /* Total-variation gradient, gridencoder.cu:506-645.  Never called by the reference's
  * trainer; exported for interface completeness and

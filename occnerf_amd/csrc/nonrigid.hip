@@ -146,9 +146,9 @@ struct NrParams {
     float hann[6];
 };
 
-__global__ __launch_bounds__(256, 2) void nonrigid_kernel(const float *__restrict__ xyz_in, int64_t N,
+__global__ __launch_bounds__(256, 2) void nonrigid_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N,
                                                           const float *__restrict__ pk, NrParams prm,
-                                                          float *__restrict__ xyz_out) {
+                                                          float *xyz_out) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -292,10 +292,10 @@ __device__ __forceinline__ void nr_glds16(const void *gbase, unsigned lane_off, 
 
 #define NR_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-__global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *__restrict__ xyz_in, int64_t N,
+__global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N,
                                                                  const float *__restrict__ pk,
                                                                  const bf16x8 *__restrict__ pkh, NrParams prm,
-                                                                 float *__restrict__ xyz_out) {
+                                                                 float *xyz_out) {
     __shared__ __attribute__((aligned(16))) bf16x8 smem[kNrRing * kNrChunkUnits + NrAux::kTotal / 4];
     bf16x8 *ring = smem;
     float *aux = reinterpret_cast<float *>(smem + kNrRing * kNrChunkUnits);

@@ -116,11 +116,11 @@ struct Params {
 
 // rows / n_dev (both nullable): evaluate only the samples rows[0 .. *n_dev) of xyz (the frame's live samples,
 // occnerf_live_rows); the launch is sized for N_max and workgroups beyond the device-side count leave at once.
-__global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const float *__restrict__ xyz_in, int64_t N_max,
+__global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N_max,
                                                                       const int32_t *__restrict__ rows,
                                                                       const int32_t *__restrict__ n_dev,
                                                                       const float *__restrict__ pk, Params prm,
-                                                                      float *__restrict__ xyz_out) {
+                                                                      float *xyz_out) {
     const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
     if ((int64_t)blockIdx.x * (32 * kWaves) >= N) return;          // uniform for the workgroup
     // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read)

@@ -133,6 +133,9 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
                          dy_dx=None, grad_inputs=None, gridtype=0, align_corners=False, interp=0):
     """`_gridencoder.grid_encode_backward` (bindings.cpp:7)."""
     _fp32_embeddings(embeddings, 'grid_encode_backward')
+    # room for the tile-set pre-pass of the tiled backward (large D = 4, C = 2 batches only)
+    scratch = torch.empty(int(L) * int(B), device=inputs.device, dtype=torch.int64) if (int(D) == 4 and int(Cc) == 2
+                                                                                      and int(B) >= 32768) else None
     with _guard(inputs):
         rc = _lib.lib().occnerf_grid_encode_backward_h(
             _chk(grad, torch.float32, 'grad'), _chk(inputs, torch.float32, 'inputs'),
@@ -140,7 +143,8 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
             _host_offsets(offsets), _chk(grad_embeddings, torch.float32, 'grad_embeddings'), int(B), int(D), int(Cc),
             int(L), float(S), int(H), _opt(dy_dx, torch.float32, 'dy_dx'),
             _opt(grad_inputs, torch.float32, 'grad_inputs'), int(gridtype),
-            int(bool(align_corners)), int(interp), _stream(inputs))
+            int(bool(align_corners)), int(interp), None if scratch is None else scratch.data_ptr(),
+            0 if scratch is None else scratch.numel() * 8, _stream(inputs))
     _lib.check(rc, 'grid_encode_backward')
 
 

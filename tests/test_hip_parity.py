@@ -721,6 +721,22 @@ def test_grid_backward_tiled_vs_scatter(ops):
     scale = scat.abs().max().item()
     assert (tiled - scat).abs().max().item() <= 2e-5 * scale    # fp32 sums in different orders
     assert tiled.abs().sum().item() > 0
+    # the same tiled kernel without the tile-set pre-pass (no scratch from the caller): every job re-hashes every sample
+    from occnerf_amd import _lib
+    gt2 = gt.clone()
+    gt2[:, 5::11] = 0.0                                         # exact-zero gradient rows are skipped by both
+    outs = []
+    for use_scratch in (False, True):
+        o = torch.zeros(total, C, device=DEV)
+        scratch = torch.empty(L * B, dtype=torch.int64, device=DEV) if use_scratch else None
+        rc = _lib.lib().occnerf_grid_encode_backward_h(
+            gt2.data_ptr(), xt.data_ptr(), emb.data_ptr(), offsets.data_ptr(), ops._host_offsets(offsets), o.data_ptr(), B, D, C,
+            L, S_, H, None, None, 0, 0, 0, None if scratch is None else scratch.data_ptr(), 0 if scratch is None else L * B * 8,
+            torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(o)
+    assert (outs[0] - outs[1]).abs().max().item() <= 1e-6 * scale, 'masked and plain scans add the same terms (fp64 tiles)'
+    assert outs[0].abs().sum().item() > 0
 
 
 def test_skip_empty_samples_is_exact(ops):
