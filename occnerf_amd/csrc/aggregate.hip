@@ -57,9 +57,9 @@ __global__ __launch_bounds__(1024) void agg_backward_tiled_kernel(const float *_
     __syncthreads();
     const int64_t n0 = (int64_t)blockIdx.x * samples_per_slice;
     const int64_t n1 = n0 + samples_per_slice < N ? n0 + samples_per_slice : N;
-    // The loop is latency-bound (three dependent-free loads per sample, then a handful of LDS atomics): four samples
-    // per trip keep 12 loads in flight per wave.  K <= 64 (one id per lane) on this path; larger K falls back below.
-    constexpr int U = 4;
+    // The loop is latency-bound (three dependent-free loads per sample, then a handful of LDS atomics): eight samples
+    // per trip keep 24 loads in flight per wave.  K <= 64 (one id per lane) on this path; larger K falls back below.
+    constexpr int U = 8;
     if (K <= 64) {
         for (int64_t nb = n0 + (int64_t)wave * U; nb < n1; nb += (int64_t)nwaves * U) {
             float g[U], my_w[U];
@@ -125,10 +125,12 @@ OCC_API int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *kn
 }
 
 OCC_API int32_t occnerf_agg_backward_slices(int64_t N) {
-    // sample slices W: with ceil(P / tile) = 14 point tiles this gives 336 workgroups (18 slices = one round of 252 was
-    // measured slower: 5.4 vs 4.7 ms at 786 K samples -- a workgroup's time is the latency of its sample loop)
-    int64_t w = (N + 32767) / 32768;
-    return (int32_t)(w < 1 ? 1 : (w > 24 ? 24 : w));
+    // Sample slices W (x 14 point tiles = workgroups).  Per-job times measured with wall_clock64 at 786 K samples and 24
+    // slices: ~1.0 ms for most (point tile, slice) jobs but 3.8 ms for every slice of ONE tile (the points most samples are
+    // near), which set the kernel's 4.7 ms.  48 slices halve every job, the hot ones then spread over two rounds of the 256
+    // CUs: 2.9 ms.  (18 slices = a single round was slower, 5.4 ms.)
+    int64_t w = (N + 16383) / 16384;
+    return (int32_t)(w < 1 ? 1 : (w > 48 ? 48 : w));
 }
 
 OCC_API int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t *knn, const float *atts, int64_t N,
