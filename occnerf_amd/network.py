@@ -305,6 +305,11 @@ class Network(nn.Module):
         ~8x8 pixel patch, which is what the kNN tiles and the hash-grid gathers want.  Rays are
         independent, so the order is free; outputs are returned in the caller's order.
         All on the device, no host sync."""
+        with torch.autocast('cuda', enabled=False):            # (a caller's autocast must not quantise the sort keys)
+            return Network._ray_patch_order_fp32(rays_d.float())
+
+    @staticmethod
+    def _ray_patch_order_fp32(rays_d):
         d = rays_d / rays_d.norm(dim=1, keepdim=True).clamp_min(1e-20)
         m = d.mean(dim=0)
         axis = torch.zeros(3, device=d.device, dtype=d.dtype).scatter_(0, m.abs().argmin().view(1), 1.0)
@@ -411,15 +416,20 @@ class Network(nn.Module):
             # decoder), then HIP forward + HIP backward per stage (train_path.py) ----
             from . import train_path
             with torch.set_grad_enabled(want_grad):
-                if refine:                                                       # network.py:557-596
-                    refined = self.pose_decoder(dst_posevec)['Rs']
-                    tb = cfg.total_bones - 1
-                    no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3),
-                                           refined.reshape(-1, 3, 3)).reshape(-1, tb, 3, 3)
-                    dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
-                cond = dst_posevec if iter_val >= nr.kick_in_iter else torch.zeros_like(dst_posevec)
-                Rs, Ts = self.motion_basis_computer(dst_Rs, dst_Ts, cnl_gtfms)
-                vol = self.mweight_vol_decoder(motion_weights_priors=motion_weights_priors)[0]
+                # the per-frame modules always run in fp32 (bone transforms in bf16 would move every sample); a caller's
+                # torch.autocast(bfloat16) selects the arithmetic of the MLP trunks only (train_path._use_bf16)
+                with torch.autocast('cuda', enabled=False):
+                    dst_Rs, dst_Ts, cnl_gtfms = dst_Rs.float(), dst_Ts.float(), cnl_gtfms.float()
+                    dst_posevec = dst_posevec.float()
+                    if refine:                                                   # network.py:557-596
+                        refined = self.pose_decoder(dst_posevec)['Rs']
+                        tb = cfg.total_bones - 1
+                        no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3),
+                                               refined.reshape(-1, 3, 3)).reshape(-1, tb, 3, 3)
+                        dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
+                    cond = dst_posevec if iter_val >= nr.kick_in_iter else torch.zeros_like(dst_posevec)
+                    Rs, Ts = self.motion_basis_computer(dst_Rs, dst_Ts, cnl_gtfms)
+                    vol = self.mweight_vol_decoder(motion_weights_priors=motion_weights_priors.float())[0]
                 rays8 = torch.cat([rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float(),
                                    near.reshape(-1, 1).float(), far.reshape(-1, 1).float()], -1)
                 order = morton_order(rays8[:, 3:6])

@@ -230,6 +230,7 @@ def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor,
     """Differentiable counterpart of Network._render_rays (+ the training branch a18).
     bbox_min, bbox_scale, bgcolor: HOST float32[3]; hann: HOST list of the 6 window weights."""
     cfg, ctx = net.cfg, net._context()
+    bf16 = _use_bf16(cfg)                 # (asked before autocast is switched off for the fp32 stages below)
     S = int(cfg.N_samples)
     n = rays8.shape[0]
     dev = rays8.device
@@ -250,7 +251,7 @@ def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor,
         knn = ops.msknn_clustered(xyz, n, S, ctx['clusters'], ctx['seed'])
     with torch.autocast('cuda', enabled=False):
         knn_base, sdf = point_sdf_block(net)
-        raw = canonical_mlp_hip(net.cnl_mlp.module, xyz, knn, net, knn_base, sdf, ctx, _use_bf16(cfg))
+        raw = canonical_mlp_hip(net.cnl_mlp.module, xyz, knn, net, knn_base, sdf, ctx, bf16)
         rgb, acc, depth, term = train_ops.composite(raw, mask, z, rays8, bgcolor)
         if net.training:
             comp_loss = _training_branch(net, raw.reshape(n, S, 5), depth, term.reshape(n, 1), cnl.reshape(n, S, 3))

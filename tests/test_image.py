@@ -78,12 +78,15 @@ def test_run_py_tpose_entry_point(tmp_path):
 
 
 @pytest.mark.gpu
-def test_train_py_entry_point(tmp_path):
-    """python train.py --cfg ... runs optimisation steps through the differentiable path, the loss
-    falls, and the checkpoint has the reference's layout and loads back with strict=True."""
+@pytest.mark.parametrize('bf16', ['False', 'True'])
+def test_train_py_entry_point(tmp_path, bf16):
+    """python train.py --cfg ... runs optimisation steps through the differentiable path (fp32 trunks, and bf16 trunks
+    under torch.autocast: BASELINE configs[4]), the loss falls, and the checkpoint has the reference's layout and loads
+    back with strict=True."""
     cmd = [sys.executable, os.path.join(ROOT, 'train.py'), '--cfg',
            os.path.join(ROOT, 'configs/occnerf/synthetic/occnerf.yaml'), 'render_size', '128', 'N_samples', '32',
-           'train.maxiter', '12', 'train.log_interval', '1', 'patch.size', '16', 'patch.N_patches', '4']
+           'train.maxiter', '12', 'train.log_interval', '1', 'patch.size', '16', 'patch.N_patches', '4',
+           'train.bf16', bf16]
     out = subprocess.check_output(cmd, cwd=str(tmp_path), env={**os.environ, 'PYTHONPATH': ROOT}, text=True)
     losses = [float(line.split('loss')[1].split()[0]) for line in out.splitlines() if line.startswith('iter')]
     assert len(losses) >= 12 and all(np.isfinite(losses))

@@ -437,3 +437,39 @@ def test_volume_decoder_gemm_gather_matches_conv_transpose():
     assert _rel(outs[1], outs[0]) <= 2e-5
     for ga, gb in zip(*grads):
         assert _rel(gb, ga) <= 2e-5
+
+
+def test_autocast_selects_bf16_trunks():
+    """train.py's `train.bf16` wraps the step in torch.autocast(bfloat16): the trunks then run in bf16 (their kernels are
+    the `linear_kernel<true, ...>` instantiation), the per-frame modules and every other stage stay fp32, and the step
+    matches the explicit cfg.train_precision = 'bf16' bit for bit."""
+    from occnerf_amd import synth, train_ops
+    seen = []
+    real = train_ops.canonical_trunks
+
+    def spy(cm, agg, var, enc, bf16):
+        seen.append(bool(bf16))
+        return real(cm, agg, var, enc, bf16)
+    train_ops.canonical_trunks = spy
+    try:
+        outs = []
+        for mode in ('autocast', 'cfg'):
+            net, ctx = build_network(0, False, S=32, non_rigid=True)
+            net.cfg.perturb = 0.0
+            net.cfg.train_precision = 'bf16' if mode == 'cfg' else 'auto'
+            net.train()
+            frame = synth.make_frame(img_size=32, pose72=synth.seeded_pose(2), orbit_frame=3)
+            data = frame_to_device(frame, DEV)
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=(mode == 'autocast')):
+                out = net(**data, iter_val=1e7)
+                loss = (out['rgb'].float() ** 2).mean()
+            loss.backward()
+            assert out['rgb'].dtype == torch.float32
+            outs.append((out['rgb'].detach().clone(), net.cnl_mlp.module.pts_linears[0].weight.grad.clone()))
+        assert seen == [True, True]
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        net.cfg.train_precision = 'auto'
+        out = net(**data, iter_val=1e7)                           # no autocast, 'auto' -> fp32 trunks
+        assert seen[-1] is False
+    finally:
+        train_ops.canonical_trunks = real
