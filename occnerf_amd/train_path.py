@@ -67,7 +67,8 @@ def point_sdf_block(net):
     norms = net.point_norms.to(pc.device)[kidx]                                  # float64
     att = torch.abs(F.cosine_similarity(direction, norms, dim=-1))[..., None]
     knn_base = (att * nbr).sum(1) / att.sum(1)
-    inside = (torch.einsum('ijk,ijk->ij', direction.float(), norms.float()) < 0).sum(1) > 1.5
+    # (row-wise dot products; the reference's einsum 'ijk,ijk->ij' runs as 20 670 batched 1x3x1 GEMMs: 0.28 ms)
+    inside = ((direction.float() * norms.float()).sum(-1) < 0).sum(1) > 1.5
     dist = torch.norm(direction, dim=-1).mean(1, keepdim=True)
     dist = torch.where(inside[:, None], -dist, dist)
     return knn_base, dist
