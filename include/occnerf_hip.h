@@ -229,7 +229,13 @@ int occnerf_point_table(const double *knn_base, const float *point_sdf, const fl
  * rows (nullable, renderer's path only): a compact list of N sample indices into xyz / knn_idxs -- the
  * samples that can contribute to their pixel (motion-weight sum != 0); output row m then belongs to
  * sample rows[m].  n_dev (nullable, needs rows): the length of the list in device memory; N is then the
- * capacity of the outputs. */
+ * capacity of the outputs.
+ * point_geo[P,16] / point_tail[P,4] (nullable, together; from occnerf_point_pack): the per-point inputs repacked so that
+ * one gather brings everything the prelude / the softmax needs of a point; with them (and 4 scales, no gathered
+ * inputs) the 8-lanes-per-sample kernel runs, without them the thread-per-sample one (same results bit for bit). */
+int occnerf_point_pack(const float *point_base, const double *normals, const double *unit_normals,
+                       const float *counter, const float *table, int32_t P, float *point_geo,
+                       float *point_tail, void *stream);
 int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs, int32_t nscale,
                             const float *point_base, const double *normals,
                             const double *unit_normals, const float *counter,
@@ -237,7 +243,8 @@ int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs
                             const float *embeddings, const int32_t *offsets,
                             const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
                             const int32_t *geo_idxs, const float *att_in, const int32_t *rows,
-                            const int32_t *n_dev, float *mlp_in, float *raw, float *enc_in, void *stream);
+                            const int32_t *n_dev, const float *point_geo, const float *point_tail,
+                            float *mlp_in, float *raw, float *enc_in, void *stream);
 
 /* Differentiable neighbour aggregation of the training path (occnerf_mlp.py:86-126 simple_agg with the
  * gather of :176-178): agg[n,:] = sum_j atts[n,j] * feats[knn[n,j],:] for feats[P,F] (F <= 64), knn[N,K],

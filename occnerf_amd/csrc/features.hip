@@ -283,6 +283,24 @@ __global__ __launch_bounds__(256) void sample_features_kernel(
 }
 
 
+// Per-point records of the 8-lanes-per-sample kernel (constant per model / per counter version):
+//   geo[P]   64 bytes: base xyz (fp32) + pad | normal x, y | normal z, unit-normal x | unit-normal y, z (fp64)
+//   tailc[P] 16 bytes: table columns 32..34 (the learnable-xyz tail of the aggregated row) + the visibility count
+__global__ void point_pack_kernel(const float *__restrict__ point_base, const double *__restrict__ normals,
+                                  const double *__restrict__ unit, const float *__restrict__ counter,
+                                  const float *__restrict__ table, int P, float *__restrict__ geo,
+                                  float4 *__restrict__ tailc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float *r = geo + (size_t)i * 16;
+    r[0] = point_base[i * 3], r[1] = point_base[i * 3 + 1], r[2] = point_base[i * 3 + 2], r[3] = 0.0f;
+    double *d = reinterpret_cast<double *>(r + 4);
+    d[0] = normals[i * 3], d[1] = normals[i * 3 + 1], d[2] = normals[i * 3 + 2];
+    d[3] = unit[i * 3], d[4] = unit[i * 3 + 1], d[5] = unit[i * 3 + 2];
+    const float *t = table + (size_t)i * kTableStride + 32;
+    tailc[i] = make_float4(t[0], t[1], t[2], counter[i]);
+}
+
 // ---------------------------------------------------------------------------------------
 // sample_features, 8 lanes per sample.  The thread-per-sample kernel above keeps the memory
 // pipeline (TA) 98 % busy with ~700 line look-ups per sample, one per lane per instruction, and
@@ -315,8 +333,7 @@ __device__ __forceinline__ float grp_max8(float v) {
 
 __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
     const float *__restrict__ xyz, int64_t N_max, const int32_t *__restrict__ knn_idxs,
-    const float *__restrict__ point_base, const double *__restrict__ normals,
-    const double *__restrict__ unit, const float *__restrict__ counter,
+    const float4 *__restrict__ geo /*[P] 64-byte GeoRec*/, const float4 *__restrict__ tailc /*[P] (table cols 32..34, counter)*/,
     const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
     LevelRecs levels, FeatParams prm, const int32_t *__restrict__ rows /*nullable: compact list of samples*/,
     const int32_t *__restrict__ n_dev /*nullable: device-side count of rows*/, float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
@@ -337,27 +354,34 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
         const F3 pq = *reinterpret_cast<const F3 *>(xyz + i * 3);               // one 12-byte load
         const float p[3] = {pq.v[0], pq.v[1], pq.v[2]};
 
-        // ---- neighbour geometry: lane g owns neighbour g, lanes 0/1 also 8/9 ----
+        // ---- neighbour geometry: lane g owns neighbour g; lanes 0..3 / 4..7 also neighbour 8 / 9 ----
+        // A gather costs one L1 look-up per run of adjacent lanes on the same line (tools/gather_rate.hip), never
+        // less than 16 cycles: everything the prelude needs of a point sits in ONE 64-byte record read with 16-byte
+        // loads (3-4 instructions per neighbour instead of 9), and the lanes of a sample that repeat neighbour 8 / 9
+        // are adjacent.
         float nrm[2];
         int negf[2];
         double t_att = 0.0, t_num[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            const int jn = a == 0 ? g : 8 + (g & 1);
-            const int n = id[jn];
-            float dir[3], nbr[3];
+            const int jn = a == 0 ? g : 8 + (g >> 2);
+            const uint32_t rec = (uint32_t)id[jn] * 64u;
+            const float4 r0 = ld32(geo, rec);                                                     // base xyz
+            const double2 r1 = ld32(reinterpret_cast<const double2 *>(geo), rec + 16u);           // normal x, y
+            const double2 r2 = ld32(reinterpret_cast<const double2 *>(geo), rec + 32u);           // normal z, unit x
+            const float nbr[3] = {r0.x, r0.y, r0.z};
+            float dir[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                nbr[c] = ld32(point_base, (uint32_t)n * 12u + (uint32_t)c * 4u);
-                dir[c] = __fsub_rn(p[c], nbr[c]);
-            }
-            double dot = 0.0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) dot = __dadd_rn(dot, __dmul_rn((double)dir[c], ld32(normals, (uint32_t)n * 24u + (uint32_t)c * 8u)));
+            for (int c = 0; c < 3; c++) dir[c] = __fsub_rn(p[c], nbr[c]);
+            double dot = __dadd_rn(0.0, __dmul_rn((double)dir[0], r1.x));
+            dot = __dadd_rn(dot, __dmul_rn((double)dir[1], r1.y));
+            dot = __dadd_rn(dot, __dmul_rn((double)dir[2], r2.x));
             negf[a] = dot < 0.0;
             nrm[a] = norm3(dir[0], dir[1], dir[2]);
-            if (a == 0) {      // only neighbours 0..2 are used below; computed by every lane (uniform code)
-                t_att = fabs(cos3_unit(dir, unit + (size_t)n * 3));
+            if (a == 0 && g < 3) {      // only neighbours 0..2 enter the projection
+                const double2 r3 = ld32(reinterpret_cast<const double2 *>(geo), rec + 48u);       // unit y, z
+                const double un[3] = {r2.y, r3.x, r3.y};
+                t_att = fabs(cos3_unit(dir, un));
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const float pn = __fdiv_rn(__fadd_rn(nbr[c], prm.bound), prm.two_bound);
@@ -375,8 +399,8 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            dsum = __fadd_rn(dsum, __shfl(nrm[1], j, 8));
-            neg += __shfl(negf[1], j, 8);
+            dsum = __fadd_rn(dsum, __shfl(nrm[1], 4 * j, 8));
+            neg += __shfl(negf[1], 4 * j, 8);
         }
         double num[3] = {0.0, 0.0, 0.0}, den = 0.0;
 #pragma unroll
@@ -399,19 +423,33 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
             if (enc_in_out) *reinterpret_cast<float4 *>(enc_in_out + o * 4) = make_float4(x[0], x[1], x[2], x[3]);
         }
 
-        // ---- hash encoding: lane g -> levels 2g, 2g+1 -> features 4g..4g+3 ----
+        // ---- hash encoding ----
+        // Lane (s, g) of the wave -- sample slot s = lane >> 3, g = lane & 7 -- encodes levels 2s, 2s+1 of the sample in
+        // slot g, i.e. the 8x8 (sample, level pair) assignment is TRANSPOSED for this phase: the 8 adjacent lanes of a
+        // gather instruction then look up the SAME level for 8 consecutive samples of a ray, whose encoder inputs (a point
+        // projected onto the body surface + a clamped distance) mostly fall into the same or neighbouring cells, so that
+        // they share cache lines instead of touching 8 different levels' tables.  Two 8x8 lane transposes (the sample's
+        // input out, the two level results back) pay for it.
+        const int lane64 = threadIdx.x & 63;
+        const int tr = ((lane64 & 7) << 3) | (lane64 >> 3);          // partner lane: (s, g) <-> (g, s)
+        float xt[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) xt[d] = __shfl(x[d], tr);
         bool oob = false;
 #pragma unroll
-        for (int d = 0; d < 4; d++) oob |= (x[d] < 0.f || x[d] > 1.f);
-        float2 ev[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+        for (int d = 0; d < 4; d++) oob |= (xt[d] < 0.f || xt[d] > 1.f);
+        float2 evt[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
         if (!oob) {
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-                const LevelRec4 lr = levels.r[2 * g + a];
-                ev[a] = encode_level_d4c2(x, embeddings, lr.size, lr.scale, lr.res_mode & 0xFFFFFFu, lr.res_mode >> 24,
-                                          lr.entry0);
+                const LevelRec4 lr = levels.r[2 * (lane64 >> 3) + a];
+                evt[a] = encode_level_d4c2(xt, embeddings, lr.size, lr.scale, lr.res_mode & 0xFFFFFFu, lr.res_mode >> 24,
+                                           lr.entry0);
             }
         }
+        float2 ev[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) ev[a] = make_float2(__shfl(evt[a].x, tr), __shfl(evt[a].y, tr));
         if (live) *reinterpret_cast<float4 *>(out + 36 + 4 * g) = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);
 
         // ---- visibility softmax: lane g owns neighbours 5g..5g+4 ----
@@ -430,8 +468,8 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            a5[k] = ld32(counter, (uint32_t)id5[k] * 4u);
-            tl[k] = ld32(table, (uint32_t)id5[k] * (uint32_t)(kTableStride * 4) + 128u);
+            tl[k] = ld32(tailc, (uint32_t)id5[k] * 16u);      // (learnable-xyz tail, visibility count): one gather
+            a5[k] = tl[k].w;
             lmin = fminf(lmin, a5[k]);
         }
         const float amin = grp_min8(lmin);
@@ -543,6 +581,18 @@ OCC_API int occnerf_point_table(const double *knn_base, const float *point_sdf,
     return check_launch("point_table");
 }
 
+OCC_API int occnerf_point_pack(const float *point_base, const double *normals, const double *unit_normals,
+                               const float *counter, const float *table, int32_t P, float *point_geo,
+                               float *point_tail, void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(point_base && normals && unit_normals && counter && table && point_geo && point_tail,
+                "point_pack: null argument");
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(point_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, as_stream(stream), point_base, normals,
+                       unit_normals, counter, table, P, point_geo, reinterpret_cast<float4 *>(point_tail));
+    return check_launch("point_pack");
+}
+
 OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs,
                                     int32_t nscale, const float *point_base, const double *normals,
                                     const double *unit_normals, const float *counter,
@@ -551,6 +601,7 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                                     const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
                                     const int32_t *geo_idxs,
                                     const float *att_in, const int32_t *rows, const int32_t *n_dev,
+                                    const float *point_geo, const float *point_tail,
                                     float *mlp_in, float *raw, float *enc_in, void *stream) {
     using namespace occ;
     if (N <= 0) return 0;
@@ -563,9 +614,12 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
     const GridModes4 gm = modes_from_host_offsets(L, lv, h_offsets);
     FeatParams prm{bound, two_bound, nscale, (int)L};
     OCC_REQUIRE(!n_dev || rows, "sample_features: a device-side count needs the row list");
-    OCC_REQUIRE(!rows || (nscale == 4 && !geo_idxs && !att_in && counter && h_offsets),
-                "sample_features: a row list is only supported on the renderer's path (4 scales, per-point inputs)");
-    if (nscale == 4 && !geo_idxs && !att_in && counter && h_offsets) {      // the renderer's call: 8 lanes per sample
+    OCC_REQUIRE(!point_geo == !point_tail, "sample_features: point_geo and point_tail come together (occnerf_point_pack)");
+    const bool lanes8 = nscale == 4 && !geo_idxs && !att_in && counter && h_offsets && point_geo;
+    OCC_REQUIRE(!rows || lanes8,
+                "sample_features: a row list is only supported on the renderer's path (4 scales, per-point inputs, "
+                "packed point records)");
+    if (lanes8) {      // the renderer's call: 8 lanes per sample
         LevelRecs levels;
         for (uint32_t l = 0; l < kMaxLevels; l++)
             levels.r[l] = LevelRec4{(uint32_t)h_offsets[l], (uint32_t)(h_offsets[l + 1] - h_offsets[l]), lv.scale[l],
@@ -573,7 +627,8 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
         int64_t blocks8 = (N + 31) / 32;
         if (blocks8 > (int64_t)kNumCU * 32) blocks8 = (int64_t)kNumCU * 32;
         hipLaunchKernelGGL(sample_features8_kernel, dim3((unsigned)blocks8), dim3(256), 0, as_stream(stream), xyz,
-                           N, knn_idxs, point_base, normals, unit_normals, counter,
+                           N, knn_idxs, reinterpret_cast<const float4 *>(point_geo),
+                           reinterpret_cast<const float4 *>(point_tail),
                            reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),
                            levels, prm, rows, n_dev, mlp_in, raw, enc_in);
         return check_launch("sample_features");

@@ -208,6 +208,18 @@ class Network(nn.Module):
         self._wconst = {'key': key, 'dec': dec, 'table': table}
         return self._wconst
 
+    def _point_pack(self, wc):
+        """ops.point_pack of the cached table: per weight version AND per visibility-counter version (the counter moves
+        in training steps only, trainer-side validation renders see the new counts)."""
+        srcs = [self.point_counter, self.point_base]
+        key = (wc['table'].data_ptr(),) + tuple((t.data_ptr(), t._version) for t in srcs)
+        if wc.get('pack_key') != key:
+            ctx = self._context()
+            wc['pack'] = ops.point_pack(self.point_base.detach(), ctx['normals'], ctx['unit'],
+                                        self.point_counter.detach(), wc['table'])
+            wc['pack_key'] = key
+        return wc['pack']
+
     def _point_stage(self, ctx):
         """network.py:263-284 + occnerf_mlp.py:171-175, once per frame."""
         enc = self.cnl_mlp.module.encoder
@@ -222,7 +234,7 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ sample pipeline
     def _render_rays(self, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann,
-                     table, t_rand=None, out=None, out_rows=None):
+                     table, t_rand=None, out=None, out_rows=None, pack=None):
         """out: (rgb[R,3], alpha[R], depth[R]) of the whole frame; this pass's rays land in rows out_rows (their index
         in the caller's order) or, without a permutation, in the slice the caller passes."""
         cfg, ctx = self.cfg, self._context()
@@ -249,7 +261,7 @@ class Network(nn.Module):
                 xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
                 self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
                 enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution,
-                rows=rows, count=count)
+                rows=rows, count=count, pack=pack)
             del knn
             ops.canonical_mlp(mlp_in, pk['cnl'], raw_c, count=count)
             del mlp_in
@@ -284,7 +296,7 @@ class Network(nn.Module):
             xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
             enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution,
-            rows=rows)
+            rows=rows, pack=pack)
         del knn
         if pk['cnl_bf16'] is not None:          # opt-in split-bf16 MFMA path (cfg.mlp_precision)
             ops.canonical_mlp_bf16x3(mlp_in, pk['cnl'], pk['cnl_bf16'], raw_c)
@@ -388,6 +400,7 @@ class Network(nn.Module):
             # ---- render: 3 launches of per-frame preamble (csrc/preamble.hip), then the sample pipeline ----
             with torch.no_grad():
                 wc = self._weight_constants()
+                pack = self._point_pack(wc)
                 f32 = lambda t: t.detach().float().contiguous()          # noqa: E731
                 Rs, Ts = ops.pose_motion_bases(self.pose_decoder, f32(dst_posevec).reshape(-1), refine, f32(dst_Rs[0]),
                                                f32(dst_Ts[0]), f32(cnl_gtfms[0]))
@@ -405,10 +418,10 @@ class Network(nn.Module):
                     n = min(rays_per_pass, R - i)
                     if order is not None:
                         self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                          wc['table'], out=out, out_rows=order[i:i + n])
+                                          wc['table'], out=out, out_rows=order[i:i + n], pack=pack)
                     else:
                         self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                          wc['table'], out=tuple(t[i:i + n] for t in out))
+                                          wc['table'], out=tuple(t[i:i + n] for t in out), pack=pack)
                 rgb, acc, depth = out
                 comp_loss = torch.zeros(1, device=dev)
         else:

@@ -376,13 +376,33 @@ def point_table(knn_base, sdf, learnable, bound32, two_bound32, embeddings, offs
     return table
 
 
+def point_pack(point_base, normals, unit, counter, table):
+    """Per-point records of the 8-lanes-per-sample feature kernel: (geo[P,16], tail[P,4]) -- see the header."""
+    P, dev = point_base.shape[0], point_base.device
+    geo = torch.empty(P, 16, device=dev, dtype=torch.float32)
+    tail = torch.empty(P, 4, device=dev, dtype=torch.float32)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_point_pack(
+            _chk(point_base, torch.float32, 'point_base'), _chk(normals, torch.float64, 'normals'),
+            _chk(unit, torch.float64, 'unit_normals'), _chk(counter, torch.float32, 'counter'),
+            _chk(table, torch.float32, 'table'), P, geo.data_ptr(), tail.data_ptr(), _stream(point_base))
+    _lib.check(rc, 'point_pack')
+    return geo, tail
+
+
 def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bound32, two_bound32,
                     embeddings, offsets, S, H, raw=None, want_enc_in=False, geo_idxs=None,
-                    att_in=None, rows=None, count=None):
+                    att_in=None, rows=None, count=None, pack=None):
     """rows (int32[M], optional): compact list of samples to evaluate; outputs then have M rows.
-    count (int32[1] on the device, optional, with rows): the list's real length; M is then a capacity."""
+    count (int32[1] on the device, optional, with rows): the list's real length; M is then a capacity.
+    pack: point_pack(...) of the same per-point inputs (built here when the renderer's kernel applies and the caller
+    did not cache it)."""
     N = xyz.shape[0] if rows is None else rows.shape[0]
     dev = xyz.device
+    if (pack is None and N > 0 and knn_idxs.shape[1] == 4 and geo_idxs is None and att_in is None
+            and counter is not None and table.dim() == 2 and table.shape[1] == table_stride()):
+        pack = point_pack(point_base, normals, unit, counter, table)
+    geo, tail = pack if pack is not None else (None, None)
     if table.dim() != 2 or table.shape[1] != table_stride():
         raise RuntimeError(f'sample_features: table must be [P,{table_stride()}] (ops.point_table), got {tuple(table.shape)}')
     mlp_in = torch.empty(N, 68, device=dev, dtype=torch.float32)
@@ -397,7 +417,9 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
             float(bound32), float(two_bound32), _chk(embeddings, torch.float32, 'embeddings'),
             _chk(offsets, torch.int32, 'offsets'), _host_offsets(offsets), int(offsets.shape[0] - 1),
             float(S), int(H), _opt(geo_idxs, torch.int32, 'geo_idxs'), _opt(att_in, torch.float32, 'att_in'),
-            _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'), mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
+            _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'),
+            _opt(geo, torch.float32, 'point_geo'), _opt(tail, torch.float32, 'point_tail'),
+            mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
             None if enc_in is None else enc_in.data_ptr(), _stream(xyz))
     _lib.check(rc, 'sample_features')
     return mlp_in, raw, enc_in
