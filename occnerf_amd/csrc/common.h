@@ -99,10 +99,15 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align_cor
 // roundings, 28 instead of 48 multiplies) and the index through per-axis partial terms.
 // `grid` + entry0 is this level's slice: with a wave-uniform `grid` (the whole table) and a per-lane
 // 32-bit entry0 the gathers take the SGPR-base + 32-bit-offset form of global_load.
-__device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const float2 *grid,
-                                                    uint32_t hashmap_size, float scale,
-                                                    uint32_t resolution, uint32_t mode, uint32_t entry0 = 0) {
-    float f[4][2];        // per axis: weight of the lower / upper cell
+// The two halves of a level: `taps` forms the cell fractions and puts the 16 corner gathers in flight, `reduce` forms the
+// weights and sums in the reference's corner order.  Kernels that have other loads to issue call them apart.
+struct LevelTaps4 {
+    float fr[4];          // fractional position in the cell, per axis
+    float2 v[16];         // corner values, corner idx = b0 | b1 << 1 | b2 << 2 | b3 << 3
+};
+__device__ __forceinline__ void encode_level_d4c2_taps(const float (&x)[4], const float2 *grid,
+                                                       uint32_t hashmap_size, float scale, uint32_t resolution,
+                                                       uint32_t mode, uint32_t entry0, LevelTaps4 &tp) {
     uint32_t pg[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) {
@@ -110,8 +115,7 @@ __device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const f
         const float fl = floorf(pos);
         pg[d] = (uint32_t)fl;
         pos -= fl;
-        f[d][0] = __fsub_rn(1.f, pos);
-        f[d][1] = pos;
+        tp.fr[d] = pos;
     }
     // per-axis index terms t[d][lower/upper]
     uint32_t t[4][2];
@@ -131,14 +135,9 @@ __device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const f
             t[d][1] = (pg[d] + 1) * primes[d];
         }
     }
-    float2 r = make_float2(0.f, 0.f);
-    float w01[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) w01[i] = __fmul_rn(f[0][i & 1], f[1][i >> 1]);     // (a0 * a1)
 #pragma unroll
     for (uint32_t idx = 0; idx < 16; idx++) {
         const int b0 = idx & 1, b1 = (idx >> 1) & 1, b2 = (idx >> 2) & 1, b3 = (idx >> 3) & 1;
-        const float w = __fmul_rn(__fmul_rn(w01[b0 | (b1 << 1)], f[2][b2]), f[3][b3]);
         uint32_t index;
         if (mode == kGridDense) {
             index = t[0][b0] + t[1][b1] + t[2][b2] + t[3][b3];
@@ -148,11 +147,35 @@ __device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const f
             const uint32_t pl[4] = {pg[0] + b0, pg[1] + b1, pg[2] + b2, pg[3] + b3};
             index = grid_index<4>(0, false, hashmap_size, resolution, pl);
         }
-        const float2 v = ld32(grid, (entry0 + index) * 8u);
-        r.x = __fmaf_rn(w, v.x, r.x);
-        r.y = __fmaf_rn(w, v.y, r.y);
+        tp.v[idx] = ld32(grid, (entry0 + index) * 8u);
+    }
+}
+__device__ __forceinline__ float2 encode_level_d4c2_reduce(const LevelTaps4 &tp) {
+    float f[4][2];        // per axis: weight of the lower / upper cell
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        f[d][0] = __fsub_rn(1.f, tp.fr[d]);
+        f[d][1] = tp.fr[d];
+    }
+    float2 r = make_float2(0.f, 0.f);
+    float w01[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w01[i] = __fmul_rn(f[0][i & 1], f[1][i >> 1]);     // (a0 * a1)
+#pragma unroll
+    for (uint32_t idx = 0; idx < 16; idx++) {
+        const int b0 = idx & 1, b1 = (idx >> 1) & 1, b2 = (idx >> 2) & 1, b3 = (idx >> 3) & 1;
+        const float w = __fmul_rn(__fmul_rn(w01[b0 | (b1 << 1)], f[2][b2]), f[3][b3]);
+        r.x = __fmaf_rn(w, tp.v[idx].x, r.x);
+        r.y = __fmaf_rn(w, tp.v[idx].y, r.y);
     }
     return r;
+}
+__device__ __forceinline__ float2 encode_level_d4c2(const float (&x)[4], const float2 *grid,
+                                                    uint32_t hashmap_size, float scale,
+                                                    uint32_t resolution, uint32_t mode, uint32_t entry0 = 0) {
+    LevelTaps4 tp;
+    encode_level_d4c2_taps(x, grid, hashmap_size, scale, resolution, mode, entry0, tp);
+    return encode_level_d4c2_reduce(tp);
 }
 
 // torch's fp32 2-norm of a 3-vector: sqrt(fma(z,z,fma(y,y,x*x))) (oracle: oc_norm3).

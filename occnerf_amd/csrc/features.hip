@@ -140,6 +140,51 @@ struct LevelRec4 {
 struct LevelRecs {
     LevelRec4 r[kMaxLevels];
 };
+// The same for the branch-free index arithmetic of the 8-lanes-per-sample kernel (levels that are dense or hashed
+// with a power-of-two size): per-axis multipliers (strides or primes; axis 0 is 1 in both) and the hash mask.
+struct LevelRec8 {
+    uint32_t entry0, mask;
+    float scale;
+    uint32_t dense;
+    uint32_t mul1, mul2, mul3, pad;
+};
+struct LevelRecs8 {
+    LevelRec8 r[kMaxLevels];
+};
+// Corner gathers of one level without a branch: a wave holds dense and hashed levels side by side, and the mode
+// branches of encode_level_d4c2_taps left every corner's gather behind its own exec-masked block with a full
+// s_waitcnt -- 32 serialized round trips per sample group.  Both candidate indices are formed from shared pair terms
+// and selected.  Same integers as grid_index (uint32 wrap-around), same fractions as encode_level_d4c2_taps.
+__device__ __forceinline__ void level_taps_select(const float (&x)[4], const float2 *grid, const LevelRec8 lr,
+                                                  LevelTaps4 &tp) {
+    const uint32_t mul[4] = {1u, lr.mul1, lr.mul2, lr.mul3};
+    uint32_t t[4][2];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        float pos = __fmaf_rn(x[d], lr.scale, 0.5f);
+        const float fl = floorf(pos);
+        const uint32_t pg = (uint32_t)fl;
+        pos -= fl;
+        tp.fr[d] = pos;
+        t[d][0] = pg * mul[d];
+        t[d][1] = t[d][0] + mul[d];
+    }
+    uint32_t a01[4], x01[4], a23[4], x23[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a01[i] = t[0][i & 1] + t[1][i >> 1];
+        x01[i] = t[0][i & 1] ^ t[1][i >> 1];
+        a23[i] = t[2][i & 1] + t[3][i >> 1];
+        x23[i] = t[2][i & 1] ^ t[3][i >> 1];
+    }
+#pragma unroll
+    for (int idx = 0; idx < 16; idx++) {
+        const uint32_t ia = a01[idx & 3] + a23[idx >> 2];
+        const uint32_t ix = (x01[idx & 3] ^ x23[idx >> 2]) & lr.mask;
+        const uint32_t index = lr.dense ? ia : ix;
+        tp.v[idx] = ld32(grid, (lr.entry0 + index) * 8u);
+    }
+}
 
 __global__ __launch_bounds__(256) void sample_features_kernel(
     const float *__restrict__ xyz, int64_t N, const int32_t *__restrict__ knn_idxs,
@@ -331,28 +376,66 @@ __device__ __forceinline__ float grp_max8(float v) {
     return fmaxf(v, __shfl_xor(v, 4, 8));
 }
 
-__global__ __launch_bounds__(256, 4) void sample_features8_kernel(
+template <bool GENERIC /* some level is neither dense nor power-of-two hashed: the reference's loop + modulo */>
+__global__ __launch_bounds__(256, 3) void sample_features8_kernel(
     const float *__restrict__ xyz, int64_t N_max, const int32_t *__restrict__ knn_idxs,
     const float4 *__restrict__ geo /*[P] 64-byte GeoRec*/, const float4 *__restrict__ tailc /*[P] (table cols 32..34, counter)*/,
     const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
-    LevelRecs levels, FeatParams prm, const int32_t *__restrict__ rows /*nullable: compact list of samples*/,
+    LevelRecs levels, LevelRecs8 levels8, FeatParams prm, const int32_t *__restrict__ rows /*nullable: compact list of samples*/,
     const int32_t *__restrict__ n_dev /*nullable: device-side count of rows*/, float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
     constexpr int NK = 4 * kKnn;                       // 40 neighbours over 4 scales
     const int g = threadIdx.x & 7;
+    const int lane64 = threadIdx.x & 63;
+    const int tr = ((lane64 & 7) << 3) | (lane64 >> 3);          // partner lane of the 8x8 transposes: (s, g) <-> (g, s)
     const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
     if (N <= 0) return;
     const int64_t group0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> 3;
     const int64_t iters = (N + ngroups - 1) / ngroups;
-    for (int64_t it = 0; it < iters; it++) {
-        const int64_t i_raw = group0 + it * ngroups;
-        const bool live = i_raw < N;
-        const int64_t o = live ? i_raw : N - 1;         // output row; keep every lane in the shuffles
-        const int64_t i = rows ? (int64_t)rows[o] : o;  // input row (sample) in xyz / knn_idxs
+
+    // A sample's journey is a chain of dependent gathers (row list -> position + neighbour ids -> point records ->
+    // hash corners; ids -> counts -> table rows) and a SIMD holds only 4 such waves, so the chain's latency, not the
+    // texture path's throughput, set the kernel's time.  The loop is software-pipelined: what the NEXT sample group
+    // needs from the streamed arrays (StageA) is requested while this group's hash corners are in flight, the row index
+    // one step further ahead, and the table rows are fetched one owner lane ahead of their use.
+    struct StageA {
+        float p[3];             // canonical position
+        int idg, id89;          // neighbour g; neighbour 8 (lanes 0..3) / 9 (lanes 4..7)
+        int id5[5];             // neighbours 5g..5g+4 of the 40
+    };
+    auto out_row = [&](int64_t it) {                    // output row of this lane's sample group; clamped: every lane
+        const int64_t i_raw = group0 + it * ngroups;    // stays in the shuffles and loads valid memory
+        return i_raw < N ? i_raw : N - 1;
+    };
+    auto load_a = [&](int64_t i, StageA &a) {
         const int32_t *id = knn_idxs + i * NK;
         struct __attribute__((packed, aligned(4))) F3 { float v[3]; };
+        struct __attribute__((packed, aligned(4))) I4 { int v[4]; };
         const F3 pq = *reinterpret_cast<const F3 *>(xyz + i * 3);               // one 12-byte load
-        const float p[3] = {pq.v[0], pq.v[1], pq.v[2]};
+        a.p[0] = pq.v[0], a.p[1] = pq.v[1], a.p[2] = pq.v[2];
+        a.idg = id[g];
+        a.id89 = id[8 + (g >> 2)];
+        const I4 q = *reinterpret_cast<const I4 *>(id + g * 5);                 // 20 contiguous bytes: 16 + 4
+        a.id5[0] = q.v[0], a.id5[1] = q.v[1], a.id5[2] = q.v[2], a.id5[3] = q.v[3];
+        a.id5[4] = id[g * 5 + 4];
+    };
+    StageA cur, nxt;
+    int32_t i1;                                         // input row of iteration it + 1
+    {
+        const int64_t o0 = out_row(0), o1 = out_row(1);
+        load_a(rows ? (int64_t)rows[o0] : o0, cur);
+        i1 = rows ? rows[o1] : (int32_t)o1;
+    }
+    for (int64_t it = 0; it < iters; it++) {
+        const bool live = group0 + it * ngroups < N;
+        const int64_t o = out_row(it);
+        const int64_t o2 = out_row(it + 2);
+        float *out = mlp_in + o * 68;
+
+        // (tail, count) of the lane's five rows: in flight with the point records
+        float4 tl[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) tl[k] = ld32(tailc, (uint32_t)cur.id5[k] * 16u);
 
         // ---- neighbour geometry: lane g owns neighbour g; lanes 0..3 / 4..7 also neighbour 8 / 9 ----
         // A gather costs one L1 look-up per run of adjacent lanes on the same line (tools/gather_rate.hip), never
@@ -364,15 +447,14 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
         double t_att = 0.0, t_num[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            const int jn = a == 0 ? g : 8 + (g >> 2);
-            const uint32_t rec = (uint32_t)id[jn] * 64u;
+            const uint32_t rec = (uint32_t)(a == 0 ? cur.idg : cur.id89) * 64u;
             const float4 r0 = ld32(geo, rec);                                                     // base xyz
             const double2 r1 = ld32(reinterpret_cast<const double2 *>(geo), rec + 16u);           // normal x, y
             const double2 r2 = ld32(reinterpret_cast<const double2 *>(geo), rec + 32u);           // normal z, unit x
             const float nbr[3] = {r0.x, r0.y, r0.z};
             float dir[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) dir[c] = __fsub_rn(p[c], nbr[c]);
+            for (int c = 0; c < 3; c++) dir[c] = __fsub_rn(cur.p[c], nbr[c]);
             double dot = __dadd_rn(0.0, __dmul_rn((double)dir[0], r1.x));
             dot = __dadd_rn(dot, __dmul_rn((double)dir[1], r1.y));
             dot = __dadd_rn(dot, __dmul_rn((double)dir[2], r2.x));
@@ -417,58 +499,16 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
 #pragma unroll
         for (int c = 0; c < 3; c++) x[c] = (float)__ddiv_rn(num[c], den);
         x[3] = nd;
-        float *out = mlp_in + o * 68;
         if (live && g == 0) {
             raw[o * 5 + 4] = dist;
             if (enc_in_out) *reinterpret_cast<float4 *>(enc_in_out + o * 4) = make_float4(x[0], x[1], x[2], x[3]);
         }
 
-        // ---- hash encoding ----
-        // Lane (s, g) of the wave -- sample slot s = lane >> 3, g = lane & 7 -- encodes levels 2s, 2s+1 of the sample in
-        // slot g, i.e. the 8x8 (sample, level pair) assignment is TRANSPOSED for this phase: the 8 adjacent lanes of a
-        // gather instruction then look up the SAME level for 8 consecutive samples of a ray, whose encoder inputs (a point
-        // projected onto the body surface + a clamped distance) mostly fall into the same or neighbouring cells, so that
-        // they share cache lines instead of touching 8 different levels' tables.  Two 8x8 lane transposes (the sample's
-        // input out, the two level results back) pay for it.
-        const int lane64 = threadIdx.x & 63;
-        const int tr = ((lane64 & 7) << 3) | (lane64 >> 3);          // partner lane: (s, g) <-> (g, s)
-        float xt[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) xt[d] = __shfl(x[d], tr);
-        bool oob = false;
-#pragma unroll
-        for (int d = 0; d < 4; d++) oob |= (xt[d] < 0.f || xt[d] > 1.f);
-        float2 evt[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
-        if (!oob) {
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const LevelRec4 lr = levels.r[2 * (lane64 >> 3) + a];
-                evt[a] = encode_level_d4c2(xt, embeddings, lr.size, lr.scale, lr.res_mode & 0xFFFFFFu, lr.res_mode >> 24,
-                                           lr.entry0);
-            }
-        }
-        float2 ev[2];
-#pragma unroll
-        for (int a = 0; a < 2; a++) ev[a] = make_float2(__shfl(evt[a].x, tr), __shfl(evt[a].y, tr));
-        if (live) *reinterpret_cast<float4 *>(out + 36 + 4 * g) = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);
-
         // ---- visibility softmax: lane g owns neighbours 5g..5g+4 ----
-        // (the lane also fetches the learnable-xyz tail, columns 32..34, of ITS five rows here: 5 gather
-        // instructions for the 40 tails of a sample instead of 40 one-lane-in-eight ones in the row loop --
-        // the texture addresser's cost is per instruction, not per byte)
-        int id5[5];
         float a5[5];
-        float4 tl[5];
         float lmin = INFINITY;
-        {       // rows 5g..5g+4: 20 contiguous bytes, dword aligned -> one 16-byte load + one dword
-            struct __attribute__((packed, aligned(4))) I4 { int v[4]; };
-            const I4 q = *reinterpret_cast<const I4 *>(id + g * 5);
-            id5[0] = q.v[0], id5[1] = q.v[1], id5[2] = q.v[2], id5[3] = q.v[3];
-            id5[4] = id[g * 5 + 4];
-        }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            tl[k] = ld32(tailc, (uint32_t)id5[k] * 16u);      // (learnable-xyz tail, visibility count): one gather
             a5[k] = tl[k].w;
             lmin = fminf(lmin, a5[k]);
         }
@@ -506,27 +546,83 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
 #pragma unroll
         for (int k = 0; k < 5; k++) a5[k] = __fdiv_rn(a5[k], ssum);
 
-        // ---- gather the 40 rows: 128 B of encoding per row across the 8 lanes ----
-        float agg[4] = {0.f, 0.f, 0.f, 0.f}, tail[3] = {0.f, 0.f, 0.f};
+        float tail[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             tail[0] += a5[k] * tl[k].x;
             tail[1] += a5[k] * tl[k].y;
             tail[2] += a5[k] * tl[k].z;
         }
+
+        // ---- hash encoding ----
+        // Lane (s, g) of the wave -- sample slot s = lane >> 3, g = lane & 7 -- encodes levels 2s, 2s+1 of the sample in
+        // slot g, i.e. the 8x8 (sample, level pair) assignment is TRANSPOSED for this phase: the 8 adjacent lanes of a
+        // gather instruction then look up the SAME level for 8 consecutive samples of a ray, whose encoder inputs (a point
+        // projected onto the body surface + a clamped distance) mostly fall into the same or neighbouring cells, so that
+        // they share cache lines (adjacent lanes on one line cost one look-up) instead of touching 8 different levels'
+        // tables.  Two 8x8 lane transposes (the sample's input out, the two level results back) pay for it.
+        float xt[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) xt[d] = __shfl(x[d], tr);
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 4; d++) oob |= (xt[d] < 0.f || xt[d] > 1.f);
+        __builtin_amdgcn_sched_barrier(0);
+        LevelTaps4 tp[2];
+        if (oob) {                      // result is 0 (gridencoder.cu:117-126); keep the (discarded) gathers inside the table
+#pragma unroll
+            for (int d = 0; d < 4; d++) xt[d] = 0.5f;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            if constexpr (GENERIC) {
+                const LevelRec4 lr = levels.r[2 * (lane64 >> 3) + a];
+                encode_level_d4c2_taps(xt, embeddings, lr.size, lr.scale, lr.res_mode & 0xFFFFFFu, lr.res_mode >> 24,
+                                       lr.entry0, tp[a]);
+            } else {
+                level_taps_select(xt, embeddings, levels8.r[2 * (lane64 >> 3) + a], tp[a]);
+            }
+        }
+        // the next group's streamed inputs: in flight behind the corners
+        load_a(i1, nxt);
+        const int32_t i2 = rows ? rows[o2] : (int32_t)o2;
+        __builtin_amdgcn_sched_barrier(0);
+
+        float2 evt[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            evt[a] = encode_level_d4c2_reduce(tp[a]);
+            if (oob) evt[a] = make_float2(0.f, 0.f);
+        }
+        float2 ev[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) ev[a] = make_float2(__shfl(evt[a].x, tr), __shfl(evt[a].y, tr));
+        if (live) *reinterpret_cast<float4 *>(out + 36 + 4 * g) = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);
+
+        // ---- gather the 40 rows: 128 B of encoding per row across the 8 lanes, one owner lane's five rows ahead ----
+        float agg[4] = {0.f, 0.f, 0.f, 0.f};
+        const uint32_t piece = (uint32_t)g * 16u;
+        float4 tb[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            tb[k] = ld32(table, (uint32_t)__shfl(cur.id5[k], 0, 8) * (uint32_t)(kTableStride * 4) + piece);
 #pragma unroll 1
-        for (int o = 0; o < 8; o++) {                   // owner lane of neighbours 5o..5o+4
+        for (int ow = 0; ow < 8; ow++) {                // owner lane of neighbours 5 ow .. 5 ow + 4
+            float4 tn[5];
+            const int own = ow < 7 ? ow + 1 : 7;        // (the last trip re-reads owner 7's rows: L1 hits, no branch)
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                tn[k] = ld32(table, (uint32_t)__shfl(cur.id5[k], own, 8) * (uint32_t)(kTableStride * 4) + piece);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                const int rowid = __shfl(id5[k], o, 8);
-                const float w = __shfl(a5[k], o, 8);
-                const uint32_t row = (uint32_t)rowid * (uint32_t)(kTableStride * 4);      // byte offset of the row
-                const float4 t = ld32(table, row + (uint32_t)g * 16u);
-                agg[0] = __fadd_rn(agg[0], __fmul_rn(w, t.x));
-                agg[1] = __fadd_rn(agg[1], __fmul_rn(w, t.y));
-                agg[2] = __fadd_rn(agg[2], __fmul_rn(w, t.z));
-                agg[3] = __fadd_rn(agg[3], __fmul_rn(w, t.w));
+                const float w = __shfl(a5[k], ow, 8);
+                agg[0] = __fadd_rn(agg[0], __fmul_rn(w, tb[k].x));
+                agg[1] = __fadd_rn(agg[1], __fmul_rn(w, tb[k].y));
+                agg[2] = __fadd_rn(agg[2], __fmul_rn(w, tb[k].z));
+                agg[3] = __fadd_rn(agg[3], __fmul_rn(w, tb[k].w));
             }
+#pragma unroll
+            for (int k = 0; k < 5; k++) tb[k] = tn[k];
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) tail[c] = grp_sum8(tail[c]);
@@ -534,6 +630,8 @@ __global__ __launch_bounds__(256, 4) void sample_features8_kernel(
             *reinterpret_cast<float4 *>(out + 4 * g) = make_float4(agg[0], agg[1], agg[2], agg[3]);
             if (g == 0) *reinterpret_cast<float4 *>(out + 32) = make_float4(tail[0], tail[1], tail[2], var);
         }
+        cur = nxt;
+        i1 = i2;
     }
 }
 
@@ -624,13 +722,24 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
         for (uint32_t l = 0; l < kMaxLevels; l++)
             levels.r[l] = LevelRec4{(uint32_t)h_offsets[l], (uint32_t)(h_offsets[l + 1] - h_offsets[l]), lv.scale[l],
                                     lv.resolution[l] | (gm.mode[l] << 24)};
+        LevelRecs8 levels8;
+        bool generic = false;
+        for (uint32_t l = 0; l < kMaxLevels; l++) {
+            const uint32_t size = (uint32_t)(h_offsets[l + 1] - h_offsets[l]), r1 = lv.resolution[l] + 1;
+            const bool dense = gm.mode[l] == kGridDense;
+            generic |= gm.mode[l] == kGridGeneric;
+            levels8.r[l] = LevelRec8{(uint32_t)h_offsets[l], dense ? 0xFFFFFFFFu : size - 1, lv.scale[l], dense ? 1u : 0u,
+                                     dense ? r1 : 2654435761u, dense ? r1 * r1 : 805459861u,
+                                     dense ? r1 * r1 * r1 : 3674653429u, 0u};
+        }
         int64_t blocks8 = (N + 31) / 32;
         if (blocks8 > (int64_t)kNumCU * 32) blocks8 = (int64_t)kNumCU * 32;
-        hipLaunchKernelGGL(sample_features8_kernel, dim3((unsigned)blocks8), dim3(256), 0, as_stream(stream), xyz,
+        auto kern = generic ? sample_features8_kernel<true> : sample_features8_kernel<false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks8), dim3(256), 0, as_stream(stream), xyz,
                            N, knn_idxs, reinterpret_cast<const float4 *>(point_geo),
                            reinterpret_cast<const float4 *>(point_tail),
                            reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),
-                           levels, prm, rows, n_dev, mlp_in, raw, enc_in);
+                           levels, levels8, prm, rows, n_dev, mlp_in, raw, enc_in);
         return check_launch("sample_features");
     }
     int64_t blocks = (N + 255) / 256;
