@@ -24,7 +24,9 @@ part of the product path.
 `all_samples`: the same frame with cfg.skip_empty_samples off.  By default the renderer does not
 evaluate the samples whose motion-weight sum is exactly 0 (their alpha is multiplied by it, so the
 pixels are bit-identical; a quarter of this frame's samples); `roofline` counts FLOPs only for the
-samples a launch processes.  `alt`: the opt-in split-bf16 MLP path.  `train`: BASELINE configs[4], one optimisation
+samples a launch processes.  `dedup`: the same frame with the renderer's default cfg.dedup_repeated_samples on (runs of
+bitwise identical samples evaluated once, bit-identical pixels); the headline keeps it OFF so that `value` stays the
+every-live-sample rate of rounds 1-2.  `alt`: the opt-in split-bf16 MLP path.  `train`: BASELINE configs[4], one optimisation
 step (forward + backward + clip + Adam, all HIP kernels) on 6 144 rays x 128 samples in bf16.  `weak_frames`
 (N > 1 only): the round-1 mode, one whole frame per rank per step.
 """
@@ -220,6 +222,9 @@ def main():
         # rows the launch really processes: the device-side live count when the renderer passes one
         mlp_events.append((e0, e1, mlp_in.shape[0] if count is None else count.clone()))
         return out
+    # The headline evaluates every live sample (the definition of rounds 1-2); the renderer's default also evaluates runs of
+    # bitwise identical samples once (cfg.dedup_repeated_samples, bit-identical pixels): reported beside it as `dedup`.
+    net.cfg.dedup_repeated_samples = False
     ops.canonical_mlp = timed_mlp
     timed_steps(renderer, frame_h, 1, args.warmup, rank, world, dev, ('bench', rank), host_out)   # warm-up (+1 step)
     mlp_events.clear()
@@ -233,6 +238,25 @@ def main():
 
     side = {}
     if not args.no_alt:
+        net.cfg.dedup_repeated_samples = True
+        if world > 1:
+            dist.barrier()
+        dtd, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, ('bench', rank), host_out)
+        if world > 1:
+            td = torch.tensor([dtd], device=dev, dtype=torch.float64)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            dtd = float(td[0])
+        heads = getattr(net, 'last_head_counts', (None, None))
+        side['dedup'] = {
+            'dedup_repeated_samples': True, 'value': R * args.steps / dtd, 'unit': 'rays/s',
+            'ms_per_step': dtd / args.steps * 1e3,
+            'distinct_positions_last_pass': None if heads[0] is None else int(heads[0]),
+            'distinct_feature_rows_last_pass': None if heads[1] is None else int(heads[1]),
+            'note': 'the renderer\'s default: consecutive live samples with bitwise identical canonical positions / feature '
+                    'rows are evaluated once (run-length, exact: rgb/alpha/depth bit-identical, tested on this frame); how '
+                    'much it removes is a property of the frame -- here most live samples sit where the motion-weight sum '
+                    'is far below the reference\'s 1e-4 clamp and collapse onto the origin'}
+        net.cfg.dedup_repeated_samples = False
         if world == 1:
             # opt-in split-bf16 MLP path (cfg.mlp_precision='bf16x3'): same frame, same steps; never part of `value`
             net.cfg.mlp_precision = 'bf16x3'
@@ -281,10 +305,12 @@ def main():
                                    'non-rigid motion on, seeded random-init checkpoint; synthetic SMPL-like body '
                                    f'and camera; {R} rays hit the body bbox (ray_mask); H2D of the ray batch and the prior and '
                                    'D2H of [R,5] inside the step; the frame\'s rays sharded over the ranks; samples whose '
-                                   'motion-weight sum is exactly 0 are dropped after the warp (bit-identical pixels, see all_samples)',
+                                   'motion-weight sum is exactly 0 are dropped after the warp (bit-identical pixels, see all_samples); every other '
+                                   'sample is evaluated (the renderer\'s run-length elimination of identical samples is OFF here, see dedup)',
                        'rays_per_frame': R, 'samples_per_ray': SPP, 'image': [IMG, IMG],
                        'samples_evaluated_per_launch': float(np.mean(nsmp)),
                        'skip_empty_samples': bool(net.cfg.get('skip_empty_samples', True)),
+                       'dedup_repeated_samples': False,
                        'world_size_formed': renderer.formed_world_size(), 'backend': backend if world > 1 else None,
                        'parallelism': f'one frame, rays sharded x{world} in 4096-ray chunks, async RCCL gather to rank 0 '
                                       'overlapped with the next frame'},

@@ -268,6 +268,25 @@ int occnerf_live_rows(const float *mask, int64_t N, int32_t *rows, int32_t *coun
 int occnerf_scatter_raw(const float *raw_c, const int32_t *rows, const int32_t *n_dev, int64_t N_max,
                         float *raw_full, void *stream);
 
+/* Repeated samples.  Every stage after the warp is a pure per-sample function (occnerf_mlp.py:144-199, mlp_offset.py:45-62),
+ * and consecutive entries of a frame's sample list often carry bitwise identical inputs (where the motion-weight sum is far
+ * below the clamp of network.py:324 the warped position collapses onto the origin).  occnerf_repeat_heads compares the key
+ * of entry m -- key_dwords 32-bit words at keys + r * stride_dwords, r = rows ? rows[m] : m -- with entry m-1's as bit
+ * patterns for m < *n_dev and writes scan[m] = number of entries 0..m that differ from their predecessor ("heads"; entry 0
+ * is one), heads[scan[m]-1] = r for every head, *head_count, and, when head_mask is given (zero-filled by the caller),
+ * head_mask[r] = 1.  scan has N_max entries (those beyond *n_dev repeat the total); temp = device scratch of
+ * occnerf_repeat_heads_temp_bytes(N_max) bytes.  occnerf_scatter_raw_heads: raw_full[rows[m], 0..3] = raw_h[h, 0..3] and
+ * raw_full[rows[m], 4] = raw_c[a, 4] with a = scanA ? scanA[m]-1 : m and h = scanB ? scanB[a]-1 : a.
+ * occnerf_canonical_mlp_rows: occnerf_canonical_mlp_counted reading input row in_rows[n] for output row n. */
+int64_t occnerf_repeat_heads_temp_bytes(int64_t N_max);
+int occnerf_repeat_heads(const void *keys, int64_t stride_dwords, int32_t key_dwords, const int32_t *rows,
+                         const int32_t *n_dev, int64_t N_max, int32_t *scan, int32_t *heads, int32_t *head_count,
+                         float *head_mask, void *temp, int64_t temp_bytes, void *stream);
+int occnerf_scatter_raw_heads(const float *raw_h, const float *raw_c, const int32_t *rows, const int32_t *n_dev,
+                              const int32_t *scanA, const int32_t *scanB, int64_t N_max, float *raw_full, void *stream);
+int occnerf_canonical_mlp_rows(const float *mlp_in, const int32_t *in_rows, int64_t N_max, const int32_t *n_dev,
+                               const float *packed, float *raw, void *stream);
+
 /* Canonical MLP weights -> MFMA operand order.  h_W/h_b: HOST arrays of the 10 device
  * weight/bias pointers in module order: pts_linears.{0,2,4,6}, geo_linear.0,
  * rgb_linears.{0,2,4,6}, output_linear.0 (torch layout [out,in]).  packed: device buffer of

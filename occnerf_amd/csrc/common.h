@@ -189,8 +189,8 @@ __device__ __forceinline__ float norm3(float x, float y, float z) {
 // buffer occnerf_canonical_mlp_pack fills.
 int64_t mlp_lds_packed_floats();
 int mlp_lds_pack(const float *const *h_W, const float *const *h_b, float *packed, hipStream_t st);
-int mlp_lds_launch(const float *mlp_in, int64_t N, const int32_t *n_dev, const float *packed, float *raw,
-                   hipStream_t st);
+int mlp_lds_launch(const float *mlp_in, const int32_t *in_rows, int64_t N, const int32_t *n_dev, const float *packed,
+                   float *raw, hipStream_t st);
 
 // LDS-staged fp32 non-rigid MLP (nonrigid16.hip); its packed stream sits behind the NrBlob of nonrigid.hip.
 int64_t nr_lds_packed_floats();

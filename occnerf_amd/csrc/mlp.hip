@@ -797,7 +797,7 @@ OCC_API int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *p
     using namespace occ;
     if (N <= 0) return 0;
     OCC_REQUIRE(mlp_in && packed && raw, "canonical_mlp: null argument");
-    return mlp_lds_launch(mlp_in, N, nullptr, packed + Blob::kTotal, raw, as_stream(stream));
+    return mlp_lds_launch(mlp_in, nullptr, N, nullptr, packed + Blob::kTotal, raw, as_stream(stream));
 }
 
 OCC_API int occnerf_canonical_mlp_counted(const float *mlp_in, int64_t N_max, const int32_t *n_dev,
@@ -805,7 +805,15 @@ OCC_API int occnerf_canonical_mlp_counted(const float *mlp_in, int64_t N_max, co
     using namespace occ;
     if (N_max <= 0) return 0;
     OCC_REQUIRE(mlp_in && n_dev && packed && raw, "canonical_mlp_counted: null argument");
-    return mlp_lds_launch(mlp_in, N_max, n_dev, packed + Blob::kTotal, raw, as_stream(stream));
+    return mlp_lds_launch(mlp_in, nullptr, N_max, n_dev, packed + Blob::kTotal, raw, as_stream(stream));
+}
+
+OCC_API int occnerf_canonical_mlp_rows(const float *mlp_in, const int32_t *in_rows, int64_t N_max, const int32_t *n_dev,
+                                       const float *packed, float *raw, void *stream) {
+    using namespace occ;
+    if (N_max <= 0) return 0;
+    OCC_REQUIRE(mlp_in && in_rows && n_dev && packed && raw, "canonical_mlp_rows: null argument");
+    return mlp_lds_launch(mlp_in, in_rows, N_max, n_dev, packed + Blob::kTotal, raw, as_stream(stream));
 }
 
 OCC_API int occnerf_canonical_mlp_direct(const float *mlp_in, int64_t N, const float *packed, float *raw,

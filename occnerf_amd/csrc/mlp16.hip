@@ -168,7 +168,10 @@ static_assert(kFrags == 4, "OCC16_ENTER waits with vmcnt(8) = 2 chunks x 4 DMAs 
 // n_dev (nullable): the number of rows actually present, in device memory (the live-sample count of the
 // frame, written by occnerf_live_rows on the same stream); the launch is sized for N_max rows and the
 // workgroups beyond *n_dev leave at once -- no host round trip to learn the count.
+// in_rows (nullable): sample n reads input row in_rows[n] (the list of distinct rows of occnerf_repeat_heads); outputs stay
+// compact (row n).
 __global__ __launch_bounds__(kWaves * 64, 2) void canonical_mlp_lds_kernel(const float *__restrict__ mlp_in,
+                                                                           const int32_t *__restrict__ in_rows,
                                                                            int64_t N_max, const int32_t *__restrict__ n_dev,
                                                                            const float *__restrict__ pk,
                                                                            float *__restrict__ raw) {
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void canonical_mlp_lds_kernel(const
     for (int i = threadIdx.x; i < Aux::kTotal; i += kWaves * 64) aux[i] = pk[Stream::kAux + i];
     float x[kKS_X + 3];
     {
-        const float *row = mlp_in + nsrc * kInGeo;
+        const float *row = mlp_in + (in_rows ? (int64_t)in_rows[nsrc] : nsrc) * kInGeo;
 #pragma unroll
         for (int G = 0; G < 4; G++) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(row + 16 * G + 4 * g);
@@ -374,13 +377,13 @@ int mlp_lds_pack(const float *const *h_W, const float *const *h_b, float *packed
     return check_launch("canonical_mlp_pack");
 }
 
-int mlp_lds_launch(const float *mlp_in, int64_t N, const int32_t *n_dev, const float *packed, float *raw,
-                   hipStream_t st) {
+int mlp_lds_launch(const float *mlp_in, const int32_t *in_rows, int64_t N, const int32_t *n_dev, const float *packed,
+                   float *raw, hipStream_t st) {
     const int64_t per_block = 16 * m16::kWaves;
     const int64_t blocks = (N + per_block - 1) / per_block;
     OCC_REQUIRE(blocks < (1LL << 31), "canonical_mlp: N too large for one launch");
-    hipLaunchKernelGGL(m16::canonical_mlp_lds_kernel, dim3((unsigned)blocks), dim3(64 * m16::kWaves), 0, st, mlp_in, N,
-                       n_dev, packed, raw);
+    hipLaunchKernelGGL(m16::canonical_mlp_lds_kernel, dim3((unsigned)blocks), dim3(64 * m16::kWaves), 0, st, mlp_in, in_rows,
+                       N, n_dev, packed, raw);
     return check_launch("canonical_mlp");
 }
 

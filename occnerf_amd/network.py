@@ -254,18 +254,38 @@ class Network(nn.Module):
             # list and count of the live samples stay on the device: no host round trip in the frame
             rows, count = ops.live_rows(mask)
             self.last_live_count = count
+            dev = xyz.device
+            dedup = bool(cfg.get('dedup_repeated_samples', True))
+            # Repeated samples (ops.repeat_heads): consecutive live samples with a bitwise identical canonical position
+            # share the neighbour search and the features, consecutive feature rows that are bitwise identical share the
+            # MLP result.
+            # Each distinct input is evaluated once and every sample receives its head's result: bit-identical pixels
+            # (cfg.dedup_repeated_samples=False evaluates every live sample; tested).
+            scan_a = scan_b = None
+            frows, fcount, kmask = rows, count, mask
             if not cfg.ignore_non_rigid_motions:
                 ops.nonrigid_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
-            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=mask)
+            if dedup:       # (the positions before the offset differ in their last bits; after it they coincide)
+                scan_a, frows, fcount, kmask = ops.repeat_heads(xyz, 3, count, rows=rows, want_mask=True)
+            self.last_head_counts = (fcount, None)
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=kmask)
             mlp_in, raw_c, _ = ops.sample_features(
                 xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
                 self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
                 enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution,
-                rows=rows, count=count, pack=pack)
+                rows=frows, count=fcount, pack=pack)
             del knn
-            ops.canonical_mlp(mlp_in, pk['cnl'], raw_c, count=count)
-            del mlp_in
-            raw = ops.scatter_raw(raw_c, rows, count, torch.zeros(N, 5, device=xyz.device))
+            if dedup:
+                scan_b, mrows, mcount, _ = ops.repeat_heads(mlp_in, 68, fcount)
+                self.last_head_counts = (fcount, mcount)
+                raw_h = torch.empty(mlp_in.shape[0], 5, device=dev)
+                ops.canonical_mlp(mlp_in, pk['cnl'], raw_h, count=mcount, in_rows=mrows)
+                del mlp_in
+                raw = ops.scatter_raw_heads(raw_h, raw_c, rows, count, scan_a, scan_b, torch.zeros(N, 5, device=dev))
+            else:
+                ops.canonical_mlp(mlp_in, pk['cnl'], raw_c, count=count)
+                del mlp_in
+                raw = ops.scatter_raw(raw_c, rows, count, torch.zeros(N, 5, device=dev))
             return ops.composite(raw, mask, z, rays8, bgcolor, out=out, out_rows=out_rows)[:3]
 
         # split-bf16 kernels (opt-in) take the list through the host: one nonzero = one sync

@@ -271,6 +271,44 @@ def scatter_raw(raw_c, rows, count, raw_full):
     return raw_full
 
 
+def repeat_heads(keys, key_cols, count, rows=None, want_mask=False):
+    """Run-length elimination of repeated samples (see the header): keys float32/int32 [M, C] (row-contiguous), the first
+    key_cols columns compared as bit patterns; entry m is row rows[m] (rows given) or m, for m < count[0] (device).
+    -> scan int32[cap], heads int32[cap], head_count int32[1], head_mask float32[M] or None; cap = len(rows) or M."""
+    dev = keys.device
+    if keys.dim() != 2 or not keys.is_contiguous() or keys.element_size() != 4:
+        raise RuntimeError('repeat_heads: keys must be a contiguous [M, C] tensor of 4-byte elements')
+    cap = keys.shape[0] if rows is None else rows.shape[0]
+    scan = torch.empty(cap, device=dev, dtype=torch.int32)
+    heads = torch.empty(cap, device=dev, dtype=torch.int32)
+    head_count = torch.empty(1, device=dev, dtype=torch.int32)
+    head_mask = torch.zeros(keys.shape[0], device=dev, dtype=torch.float32) if want_mask else None
+    if cap == 0:
+        head_count.zero_()
+        return scan, heads, head_count, head_mask
+    nbytes = int(_lib.lib().occnerf_repeat_heads_temp_bytes(cap))
+    if nbytes < 0:
+        raise RuntimeError('repeat_heads: temp size query failed')
+    temp = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_repeat_heads(
+            keys.data_ptr(), keys.shape[1], int(key_cols), _opt(rows, torch.int32, 'rows'),
+            _chk(count, torch.int32, 'count'), cap, scan.data_ptr(), heads.data_ptr(), head_count.data_ptr(),
+            None if head_mask is None else head_mask.data_ptr(), temp.data_ptr(), nbytes, _stream(keys))
+    _lib.check(rc, 'repeat_heads')
+    return scan, heads, head_count, head_mask
+
+
+def scatter_raw_heads(raw_h, raw_c, rows, count, scan_a, scan_b, raw_full):
+    with _guard(raw_c):
+        rc = _lib.lib().occnerf_scatter_raw_heads(
+            _chk(raw_h, torch.float32, 'raw_h'), _chk(raw_c, torch.float32, 'raw_c'), _chk(rows, torch.int32, 'rows'),
+            _chk(count, torch.int32, 'count'), _opt(scan_a, torch.int32, 'scan_a'), _opt(scan_b, torch.int32, 'scan_b'),
+            rows.shape[0], _chk(raw_full, torch.float32, 'raw_full'), _stream(raw_c))
+    _lib.check(rc, 'scatter_raw_heads')
+    return raw_full
+
+
 def nonrigid_pack_bf16(weights):
     dev = weights[0].device
     n = _lib.lib().occnerf_nonrigid_packed_bf16_bytes()
@@ -437,9 +475,18 @@ def canonical_mlp_pack(weights, biases):
     return packed
 
 
-def canonical_mlp(mlp_in, packed, raw, direct=False, count=None):
+def canonical_mlp(mlp_in, packed, raw, direct=False, count=None, in_rows=None):
     """fp32 MLP trunks.  direct=True: the 32-sample-wave direct-load kernel (cross-check / A-B timing).
-    count (int32[1] on the device): only the first count rows exist; the host does not know the number."""
+    count (int32[1] on the device): only the first count rows exist; the host does not know the number.
+    in_rows (int32, with count): output row n is computed from input row in_rows[n]."""
+    if in_rows is not None:
+        with _guard(mlp_in):
+            rc = _lib.lib().occnerf_canonical_mlp_rows(
+                _chk(mlp_in, torch.float32, 'mlp_in'), _chk(in_rows, torch.int32, 'in_rows'), in_rows.shape[0],
+                _chk(count, torch.int32, 'count'), _chk(packed, torch.float32, 'packed'),
+                _chk(raw, torch.float32, 'raw'), _stream(mlp_in))
+        _lib.check(rc, 'canonical_mlp_rows')
+        return raw
     if count is not None:
         with _guard(mlp_in):
             rc = _lib.lib().occnerf_canonical_mlp_counted(

@@ -801,6 +801,93 @@ def test_skip_empty_samples_is_exact_at_bench_size(ops):
         assert torch.equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize('n,kcols,ccols', [(1, 3, 3), (300, 3, 3), (70001, 68, 68), (5000, 4, 8), (257, 3, 3)])
+def test_repeat_heads(ops, n, kcols, ccols):
+    """Run-length elimination of repeated rows against numpy: scan, head list, head count, head mask -- with and without a
+    row list, 16-byte and dword compare paths, a count below the capacity, -0.0 != +0.0 (bit patterns)."""
+    rng = np.random.default_rng(n)
+    base = rng.standard_normal((max(n // 7, 1), ccols)).astype(np.float32)
+    pick = np.sort(rng.integers(0, base.shape[0], n))            # runs of equal rows
+    keys = base[pick].copy()
+    if n > 10:
+        keys[5, 0], keys[6] = 0.0, keys[5]
+        keys[6, 0] = -0.0                                          # equal as floats, different as bits
+        keys[9, ccols - 1] += 1.0                                   # a column outside the key when kcols < ccols
+    kd = torch.from_numpy(keys).to(DEV)
+    for use_rows in (False, True):
+        if use_rows:
+            rows_np = np.sort(rng.choice(n, size=max(n * 2 // 3, 1), replace=False)).astype(np.int32)
+            rows = torch.from_numpy(rows_np).to(DEV)
+        else:
+            rows_np, rows = np.arange(n, dtype=np.int32), None
+        cap = rows_np.shape[0]
+        cnt = cap if n != 257 else cap // 2                         # a list shorter than its buffer
+        count = torch.tensor([cnt], device=DEV, dtype=torch.int32)
+        scan, heads, hcount, hmask = ops.repeat_heads(kd, kcols, count, rows=rows, want_mask=True)
+        kb = keys.view(np.uint32)[rows_np[:cnt], :kcols]
+        flag = np.ones(cnt, bool)
+        flag[1:] = (kb[1:] != kb[:-1]).any(1)
+        want_scan = np.cumsum(flag)
+        assert int(hcount) == int(flag.sum())
+        assert np.array_equal(scan[:cnt].cpu().numpy(), want_scan)
+        assert np.array_equal(heads[:int(hcount)].cpu().numpy(), rows_np[:cnt][flag])
+        want_mask = np.zeros(n, np.float32)
+        want_mask[rows_np[:cnt][flag]] = 1.0
+        assert np.array_equal(hmask.cpu().numpy(), want_mask)
+        # every entry finds its head's result
+        raw_h = torch.arange(cap * 5, device=DEV, dtype=torch.float32).reshape(cap, 5)
+        raw_c = -torch.arange(cap * 5, device=DEV, dtype=torch.float32).reshape(cap, 5)
+        rows_d = rows if rows is not None else torch.arange(n, device=DEV, dtype=torch.int32)
+        full = ops.scatter_raw_heads(raw_h, raw_c, rows_d, count, scan, None, torch.zeros(n, 5, device=DEV)).cpu().numpy()
+        ref = np.zeros((n, 5), np.float32)
+        a = want_scan - 1
+        ref[rows_np[:cnt], :4] = raw_h.cpu().numpy()[a, :4]
+        ref[rows_np[:cnt], 4] = raw_c.cpu().numpy()[a, 4]
+        assert np.array_equal(full, ref)
+
+
+def test_canonical_mlp_rows(ops):
+    """occnerf_canonical_mlp_rows == occnerf_canonical_mlp_counted on the gathered rows, bit for bit."""
+    ctx = util.model_context(0, False)
+    Wg, Bg, Wc, Bc = util.canonical_mlp_params(ctx['sd'])
+    W = [torch.from_numpy(w).to(DEV) for w in Wg + Wc]
+    B = [torch.from_numpy(b).to(DEV) for b in Bg + Bc]
+    packed = ops.canonical_mlp_pack(W, B)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    mlp_in = (torch.randn(1000, 68, generator=g) * 0.3).to(DEV)
+    rows = torch.randint(0, 1000, (777,), generator=g).int().to(DEV)
+    count = torch.tensor([700], device=DEV, dtype=torch.int32)
+    a = ops.canonical_mlp(mlp_in, packed, torch.zeros(777, 5, device=DEV), count=count, in_rows=rows)
+    b = ops.canonical_mlp(mlp_in[rows.long()].contiguous(), packed, torch.zeros(777, 5, device=DEV), count=count)
+    assert torch.equal(a[:700, :4], b[:700, :4]) and float(a[700:].abs().max()) == 0.0
+    assert float(a[:700, :4].abs().max()) > 0
+
+
+@pytest.mark.parametrize('size,S,amplify', [(96, 64, True), (512, 128, False)])
+def test_dedup_repeated_samples_is_exact(ops, size, S, amplify):
+    """Evaluating each run of bitwise identical samples once (cfg.dedup_repeated_samples) changes no output bit -- on a
+    small amplified-checkpoint frame and on the frame the headline is quoted on -- and does remove work there."""
+    from occnerf_amd import synth
+    net, ctx = build_network(seed=0, amplify=amplify, S=S, non_rigid=True)
+    frame = synth.make_frame(img_size=size, pose72=synth.seeded_pose(1), orbit_frame=28)
+    data = frame_to_device(frame, DEV)
+    outs = []
+    for dedup in (True, False):
+        net.cfg.dedup_repeated_samples = dedup
+        with torch.no_grad():
+            o = net(**data, iter_val=1e7)
+        outs.append({k: o[k].clone() for k in ('rgb', 'alpha', 'depth')})
+        if dedup:
+            live, heads_a, heads_b = int(net.last_live_count), int(net.last_head_counts[0]), int(net.last_head_counts[1])
+    net.cfg.dedup_repeated_samples = True
+    assert 0 < heads_b <= heads_a <= live
+    if size == 512:
+        assert heads_a < 0.7 * live and heads_b < 0.5 * live, (live, heads_a, heads_b)
+    for k in ('rgb', 'alpha', 'depth'):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert float(outs[0]['alpha'].max()) > 0.05
+
+
 def test_config1_real_size(oracle):
     """BASELINE configs[0] at its real size: T-pose render, 128x128 image, 32 samples/ray, random-init weights --
     every ray against the full CPU oracle (1e-4, the BASELINE gate)."""
