@@ -232,7 +232,8 @@ int occnerf_point_table(const double *knn_base, const float *point_sdf, const fl
  * capacity of the outputs.
  * point_geo[P,16] / point_tail[P,4] (nullable, together; from occnerf_point_pack): the per-point inputs repacked so that
  * one gather brings everything the prelude / the softmax needs of a point; with them (and 4 scales, no gathered
- * inputs) the 8-lanes-per-sample kernel runs, without them the thread-per-sample one (same results bit for bit). */
+ * inputs) the 8-lanes-per-sample kernel runs, without them the thread-per-sample one (same results bit for bit).
+ * P: rows of point_geo / point_tail (ignored without them). */
 int occnerf_point_pack(const float *point_base, const double *normals, const double *unit_normals,
                        const float *counter, const float *table, int32_t P, float *point_geo,
                        float *point_tail, void *stream);
@@ -243,7 +244,7 @@ int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs
                             const float *embeddings, const int32_t *offsets,
                             const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
                             const int32_t *geo_idxs, const float *att_in, const int32_t *rows,
-                            const int32_t *n_dev, const float *point_geo, const float *point_tail,
+                            const int32_t *n_dev, const float *point_geo, const float *point_tail, int32_t P,
                             float *mlp_in, float *raw, float *enc_in, void *stream);
 
 /* Differentiable neighbour aggregation of the training path (occnerf_mlp.py:86-126 simple_agg with the

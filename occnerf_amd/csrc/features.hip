@@ -128,6 +128,7 @@ static GridModes4 modes_from_host_offsets(uint32_t L, const GridLevels &lv, cons
 struct FeatParams {
     float bound, two_bound;
     int nscale, L;
+    int P;              // rows of the packed point records (8-lanes-per-sample kernel)
 };
 
 // Everything sample_features8_kernel needs to know about a level, in one 16-byte record: a lane picks its
@@ -376,14 +377,36 @@ __device__ __forceinline__ float grp_max8(float v) {
     return fmaxf(v, __shfl_xor(v, 4, 8));
 }
 
-template <bool GENERIC /* some level is neither dense nor power-of-two hashed: the reference's loop + modulo */>
-__global__ __launch_bounds__(256, 3) void sample_features8_kernel(
+// quad broadcasts: lane Q of every aligned group of four lanes, one DPP move per dword
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, true));
+}
+template <int Q>
+__device__ __forceinline__ double quad_bcast_f64(float lo, float hi) {
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, hi), Q * 0x55, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, lo), Q * 0x55, 0xf, 0xf, true));
+}
+
+constexpr int kLdsTailPoints = 9216;       // (tail, count) records that fit the workgroup's LDS image (144 KiB)
+
+template <bool GENERIC /* some level is neither dense nor power-of-two hashed: the reference's loop + modulo */,
+          bool LDS_TAIL /* one 768-thread workgroup per CU keeps the (tail, count) records of all points in LDS */>
+__global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kernel(
     const float *__restrict__ xyz, int64_t N_max, const int32_t *__restrict__ knn_idxs,
     const float4 *__restrict__ geo /*[P] 64-byte GeoRec*/, const float4 *__restrict__ tailc /*[P] (table cols 32..34, counter)*/,
     const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
     LevelRecs levels, LevelRecs8 levels8, FeatParams prm, const int32_t *__restrict__ rows /*nullable: compact list of samples*/,
     const int32_t *__restrict__ n_dev /*nullable: device-side count of rows*/, float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
     constexpr int NK = 4 * kKnn;                       // 40 neighbours over 4 scales
+    // The texture path is this kernel's bound (TA busy 80-89 %, ~16 cycles per gather instruction of 8+ bytes per lane,
+    // 64 when every lane has its own line): the five (tail, count) gathers per sample group -- 64 lines each -- are LDS
+    // reads instead when the records of all points fit.
+    __shared__ float4 s_tail[LDS_TAIL ? kLdsTailPoints : 1];
+    if constexpr (LDS_TAIL) {
+        for (int i = threadIdx.x; i < prm.P; i += blockDim.x) s_tail[i] = tailc[i];
+        __syncthreads();
+    }
     const int g = threadIdx.x & 7;
     const int lane64 = threadIdx.x & 63;
     const int tr = ((lane64 & 7) << 3) | (lane64 >> 3);          // partner lane of the 8x8 transposes: (s, g) <-> (g, s)
@@ -435,61 +458,64 @@ __global__ __launch_bounds__(256, 3) void sample_features8_kernel(
         // (tail, count) of the lane's five rows: in flight with the point records
         float4 tl[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) tl[k] = ld32(tailc, (uint32_t)cur.id5[k] * 16u);
+        for (int k = 0; k < 5; k++) tl[k] = LDS_TAIL ? s_tail[cur.id5[k]] : ld32(tailc, (uint32_t)cur.id5[k] * 16u);
 
-        // ---- neighbour geometry: lane g owns neighbour g; lanes 0..3 / 4..7 also neighbour 8 / 9 ----
+        // ---- neighbour geometry: the four lanes of a quad fetch one neighbour's 64-byte record together ----
         // A gather costs one L1 look-up per run of adjacent lanes on the same line (tools/gather_rate.hip), never
-        // less than 16 cycles: everything the prelude needs of a point sits in ONE 64-byte record read with 16-byte
-        // loads (3-4 instructions per neighbour instead of 9), and the lanes of a sample that repeat neighbour 8 / 9
-        // are adjacent.
-        float nrm[2];
-        int negf[2];
-        double t_att = 0.0, t_num[3] = {0.0, 0.0, 0.0};
+        // less than 16 cycles.  Lane (h = g >> 2, q = g & 3) reads 16-byte piece q of neighbour 2k + h in trip k: five
+        // instructions of 16 runs each for the ten neighbours of the wave's 8 samples (a lane per neighbour reading its
+        // record alone: seven instructions of 64 runs).  The pieces meet through quad-broadcast DPP moves and every lane
+        // of the quad evaluates its neighbour (redundant VALU work: the kernel is bound by the texture path).
+        float nrm[5];
+        int negf[5];
+        double t_att[2] = {0.0, 0.0}, t_num[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        {
+            float4 pc[5];
 #pragma unroll
-        for (int a = 0; a < 2; a++) {
-            const uint32_t rec = (uint32_t)(a == 0 ? cur.idg : cur.id89) * 64u;
-            const float4 r0 = ld32(geo, rec);                                                     // base xyz
-            const double2 r1 = ld32(reinterpret_cast<const double2 *>(geo), rec + 16u);           // normal x, y
-            const double2 r2 = ld32(reinterpret_cast<const double2 *>(geo), rec + 32u);           // normal z, unit x
-            const float nbr[3] = {r0.x, r0.y, r0.z};
-            float dir[3];
+            for (int k = 0; k < 5; k++) {
+                const int nid = k < 4 ? __shfl(cur.idg, 2 * k + (g >> 2), 8) : cur.id89;
+                pc[k] = ld32(geo, (uint32_t)nid * 64u + (uint32_t)(g & 3) * 16u);
+            }
 #pragma unroll
-            for (int c = 0; c < 3; c++) dir[c] = __fsub_rn(cur.p[c], nbr[c]);
-            double dot = __dadd_rn(0.0, __dmul_rn((double)dir[0], r1.x));
-            dot = __dadd_rn(dot, __dmul_rn((double)dir[1], r1.y));
-            dot = __dadd_rn(dot, __dmul_rn((double)dir[2], r2.x));
-            negf[a] = dot < 0.0;
-            nrm[a] = norm3(dir[0], dir[1], dir[2]);
-            if (a == 0 && g < 3) {      // only neighbours 0..2 enter the projection
-                const double2 r3 = ld32(reinterpret_cast<const double2 *>(geo), rec + 48u);       // unit y, z
-                const double un[3] = {r2.y, r3.x, r3.y};
-                t_att = fabs(cos3_unit(dir, un));
+            for (int k = 0; k < 5; k++) {
+                const float nbr[3] = {quad_bcast<0>(pc[k].x), quad_bcast<0>(pc[k].y), quad_bcast<0>(pc[k].z)};
+                const double nx = quad_bcast_f64<1>(pc[k].x, pc[k].y), ny = quad_bcast_f64<1>(pc[k].z, pc[k].w);
+                const double nz = quad_bcast_f64<2>(pc[k].x, pc[k].y);
+                float dir[3];
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float pn = __fdiv_rn(__fadd_rn(nbr[c], prm.bound), prm.two_bound);
-                    t_num[c] = __dmul_rn(t_att, (double)pn);
+                for (int c = 0; c < 3; c++) dir[c] = __fsub_rn(cur.p[c], nbr[c]);
+                double dot = __dadd_rn(0.0, __dmul_rn((double)dir[0], nx));
+                dot = __dadd_rn(dot, __dmul_rn((double)dir[1], ny));
+                dot = __dadd_rn(dot, __dmul_rn((double)dir[2], nz));
+                negf[k] = dot < 0.0;
+                nrm[k] = norm3(dir[0], dir[1], dir[2]);
+                if (k < 2) {            // neighbours 0, 1 (trip 0) and 2 (trip 1, quad 0) enter the projection
+                    const double un[3] = {quad_bcast_f64<2>(pc[k].z, pc[k].w), quad_bcast_f64<3>(pc[k].x, pc[k].y),
+                                          quad_bcast_f64<3>(pc[k].z, pc[k].w)};
+                    t_att[k] = fabs(cos3_unit(dir, un));
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float pn = __fdiv_rn(__fadd_rn(nbr[c], prm.bound), prm.two_bound);
+                        t_num[k][c] = __dmul_rn(t_att[k], (double)pn);
+                    }
                 }
             }
         }
-        // sequential combination in neighbour order j = 0..9 (fp32 sum) / 0..2 (fp64 sums)
+        // sequential combination in neighbour order j = 0..9 (fp32 sum) / 0..2 (fp64 sums): neighbour j sits in trip
+        // j >> 1, quad j & 1
         float dsum = 0.0f;
         int neg = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            dsum = __fadd_rn(dsum, __shfl(nrm[0], j, 8));
-            neg += __shfl(negf[0], j, 8);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            dsum = __fadd_rn(dsum, __shfl(nrm[1], 4 * j, 8));
-            neg += __shfl(negf[1], 4 * j, 8);
+        for (int j = 0; j < kKnn; j++) {
+            dsum = __fadd_rn(dsum, __shfl(nrm[j >> 1], 4 * (j & 1), 8));
+            neg += __shfl(negf[j >> 1], 4 * (j & 1), 8);
         }
         double num[3] = {0.0, 0.0, 0.0}, den = 0.0;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) num[c] = __dadd_rn(num[c], __shfl(t_num[c], j, 8));
-            den = __dadd_rn(den, __shfl(t_att, j, 8));
+            for (int c = 0; c < 3; c++) num[c] = __dadd_rn(num[c], __shfl(t_num[j >> 1][c], 4 * (j & 1), 8));
+            den = __dadd_rn(den, __shfl(t_att[j >> 1], 4 * (j & 1), 8));
         }
         float dist = __fdiv_rn(dsum, (float)kKnn);
         if (2 * neg > kKnn) dist = -dist;
@@ -601,28 +627,39 @@ __global__ __launch_bounds__(256, 3) void sample_features8_kernel(
 
         // ---- gather the 40 rows: 128 B of encoding per row across the 8 lanes, one owner lane's five rows ahead ----
         float agg[4] = {0.f, 0.f, 0.f, 0.f};
+        // The table rows come in four chunks of ten (two owner lanes' rows); three chunks are in flight or in use at a
+        // time: with one chunk ahead every trip waited out most of an L2 round trip and the row phase was 46 % of the
+        // kernel (clock64 marks per phase).
         const uint32_t piece = (uint32_t)g * 16u;
-        float4 tb[5];
+        auto issue_chunk = [&](int c, float4 (&t)[10]) {
 #pragma unroll
-        for (int k = 0; k < 5; k++)
-            tb[k] = ld32(table, (uint32_t)__shfl(cur.id5[k], 0, 8) * (uint32_t)(kTableStride * 4) + piece);
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+                    t[h * 5 + k] = ld32(table, (uint32_t)__shfl(cur.id5[k], 2 * c + h, 8) * (uint32_t)(kTableStride * 4) + piece);
+            }
+        };
+        float4 b0[10], b1[10], b2[10];
+        issue_chunk(0, b0);
+        issue_chunk(1, b1);
 #pragma unroll 1
-        for (int ow = 0; ow < 8; ow++) {                // owner lane of neighbours 5 ow .. 5 ow + 4
-            float4 tn[5];
-            const int own = ow < 7 ? ow + 1 : 7;        // (the last trip re-reads owner 7's rows: L1 hits, no branch)
+        for (int c = 0; c < 4; c++) {
+            const int cn = c + 2 < 4 ? c + 2 : 3;       // (the last two trips re-read chunk 3: L1 hits, no branch)
+            issue_chunk(cn, b2);
 #pragma unroll
-            for (int k = 0; k < 5; k++)
-                tn[k] = ld32(table, (uint32_t)__shfl(cur.id5[k], own, 8) * (uint32_t)(kTableStride * 4) + piece);
+            for (int h = 0; h < 2; h++) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const float w = __shfl(a5[k], ow, 8);
-                agg[0] = __fadd_rn(agg[0], __fmul_rn(w, tb[k].x));
-                agg[1] = __fadd_rn(agg[1], __fmul_rn(w, tb[k].y));
-                agg[2] = __fadd_rn(agg[2], __fmul_rn(w, tb[k].z));
-                agg[3] = __fadd_rn(agg[3], __fmul_rn(w, tb[k].w));
+                for (int k = 0; k < 5; k++) {
+                    const float w = __shfl(a5[k], 2 * c + h, 8);
+                    const float4 t = b0[h * 5 + k];
+                    agg[0] = __fadd_rn(agg[0], __fmul_rn(w, t.x));
+                    agg[1] = __fadd_rn(agg[1], __fmul_rn(w, t.y));
+                    agg[2] = __fadd_rn(agg[2], __fmul_rn(w, t.z));
+                    agg[3] = __fadd_rn(agg[3], __fmul_rn(w, t.w));
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 5; k++) tb[k] = tn[k];
+            for (int k = 0; k < 10; k++) b0[k] = b1[k], b1[k] = b2[k];
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) tail[c] = grp_sum8(tail[c]);
@@ -699,7 +736,7 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                                     const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
                                     const int32_t *geo_idxs,
                                     const float *att_in, const int32_t *rows, const int32_t *n_dev,
-                                    const float *point_geo, const float *point_tail,
+                                    const float *point_geo, const float *point_tail, int32_t P,
                                     float *mlp_in, float *raw, float *enc_in, void *stream) {
     using namespace occ;
     if (N <= 0) return 0;
@@ -710,7 +747,7 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
     if (N <= 0) return 0;
     const GridLevels lv = make_grid_levels(L, S, H);
     const GridModes4 gm = modes_from_host_offsets(L, lv, h_offsets);
-    FeatParams prm{bound, two_bound, nscale, (int)L};
+    FeatParams prm{bound, two_bound, nscale, (int)L, (int)P};
     OCC_REQUIRE(!n_dev || rows, "sample_features: a device-side count needs the row list");
     OCC_REQUIRE(!point_geo == !point_tail, "sample_features: point_geo and point_tail come together (occnerf_point_pack)");
     const bool lanes8 = nscale == 4 && !geo_idxs && !att_in && counter && h_offsets && point_geo;
@@ -732,10 +769,15 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                                      dense ? r1 : 2654435761u, dense ? r1 * r1 : 805459861u,
                                      dense ? r1 * r1 * r1 : 3674653429u, 0u};
         }
-        int64_t blocks8 = (N + 31) / 32;
-        if (blocks8 > (int64_t)kNumCU * 32) blocks8 = (int64_t)kNumCU * 32;
-        auto kern = generic ? sample_features8_kernel<true> : sample_features8_kernel<false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks8), dim3(256), 0, as_stream(stream), xyz,
+        OCC_REQUIRE(P > 0, "sample_features: P=%d rows of packed point records", P);
+        const bool lds_tail = P <= kLdsTailPoints && N >= 96 * 64;      // (small calls: not worth a 110 KiB image per block)
+        const int threads = lds_tail ? 768 : 256;
+        int64_t blocks8 = (N * 8 + threads - 1) / threads;
+        const int64_t cap = lds_tail ? (int64_t)kNumCU : (int64_t)kNumCU * 32;
+        if (blocks8 > cap) blocks8 = cap;
+        auto kern = generic ? (lds_tail ? sample_features8_kernel<true, true> : sample_features8_kernel<true, false>)
+                            : (lds_tail ? sample_features8_kernel<false, true> : sample_features8_kernel<false, false>);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks8), dim3(threads), 0, as_stream(stream), xyz,
                            N, knn_idxs, reinterpret_cast<const float4 *>(point_geo),
                            reinterpret_cast<const float4 *>(point_tail),
                            reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),

@@ -457,6 +457,7 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
             float(S), int(H), _opt(geo_idxs, torch.int32, 'geo_idxs'), _opt(att_in, torch.float32, 'att_in'),
             _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'),
             _opt(geo, torch.float32, 'point_geo'), _opt(tail, torch.float32, 'point_tail'),
+            0 if geo is None else int(geo.shape[0]),
             mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
             None if enc_in is None else enc_in.data_ptr(), _stream(xyz))
     _lib.check(rc, 'sample_features')

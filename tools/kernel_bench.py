@@ -129,6 +129,7 @@ def bench_stage(name):
     from occnerf_amd import synth
     from tests.gpu_util import build_network, frame_to_device
     net, ctx = build_network(0, False, S=128, non_rigid=True)
+    net.cfg.dedup_repeated_samples = '--dedup' in sys.argv      # default: every live sample (17.6 M rows)
     frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
     data = frame_to_device(frame, 'cuda:0')
     real = getattr(ops, name)
