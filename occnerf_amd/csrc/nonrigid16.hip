@@ -122,7 +122,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const floa
                                                                       const float *__restrict__ pk, Params prm,
                                                                       float *xyz_out) {
     const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
-    if ((int64_t)blockIdx.x * (32 * kWaves) >= N) return;          // uniform for the workgroup
+    const int64_t ntiles = (N + 32 * kWaves - 1) / (32 * kWaves);   // a workgroup's tile: 4 waves x 32 samples
+    if ((int64_t)blockIdx.x >= ntiles) return;                      // uniform for the workgroup
     // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read)
     __shared__ __attribute__((aligned(16))) f32x4 smem[kRingSlots * kChunkF4 + Aux::kTotal / 4];
     f32x4 *ring = smem;
@@ -131,19 +132,65 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const floa
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = lane & 15, g = lane >> 4;
-    const int64_t base = ((int64_t)blockIdx.x * kWaves + wave) * 32;
 
     for (int i = threadIdx.x; i < Aux::kTotal; i += kWaves * 64) aux[i] = pk[Stream::kAux + i];
 
+    // ---- weight stream: the c-th chunk to enter lives in ring slot c & 3; the stream wraps from chunk 45 to chunk 0 ----
+    // The workgroup is PERSISTENT: it walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and the ring keeps running
+    // across them (the chunks of the next tile's first layer are requested during this tile's last), so a tile pays neither
+    // a workgroup launch nor the first chunk's DMA latency -- 8-10 % of a 128-sample workgroup's 38 us before.
+    const f32x4 *stream = reinterpret_cast<const f32x4 *>(pk);
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) f32x4 *)ring;
+    auto issue1 = [&](int c, int cs, int f) {      // 1 KiB fragment f of this wave's share of stream chunk cs -> slot of c
+        const int frag = wave * kFrags + f;
+        unsigned keep;      // M0 carries the wave-uniform LDS destination; lane i lands at +16 i
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane * 16), "s"(stream + (size_t)cs * kChunkF4 + frag * 64),
+                       "s"(ring_lds + (unsigned)(((c & (kRingSlots - 1)) * kChunkF4 + frag * 64) * 16))
+                     : "memory");
+    };
+    auto issue = [&](int c, int cs) {
+#pragma unroll
+        for (int f = 0; f < kFrags; f++) issue1(c, cs, f);
+    };
+    int c = 0;                     // chunks entered so far (ring position)
+    int ci = 4;                    // stream chunk the next refill brings (always the (c + 2)-th to enter)
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+
+    // Enter the next chunk (3 chunks x kFrags DMAs outstanding; vmcnt(2*kFrags) retires the oldest), rendezvous; after
+    // the barrier every wave has finished reading the previous chunk, whose slot the following step refills.
+    const f32x4 *slot_;
+#define NR16_ENTER()                                                   \
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");        \
+    __builtin_amdgcn_s_barrier();                                      \
+    slot_ = ring + (c & (kRingSlots - 1)) * kChunkF4;                  \
+    c++;
+#define NR16_READ_HALF(W, HALF)                                        \
+    _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) W[ob_] = slot_[((HALF) * 4 + ob_) * 64 + lane];
+
+    f32x4 wA[4];
+    NR16_ENTER()                   // (its lgkmcnt(0) + barrier also publish aux)
+    issue(3, 3);
+    NR16_READ_HALF(wA, 0)
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = (tile * kWaves + wave) * 32;
+
     // ---- inputs and embedding: tile T holds sample base + 16 T + s ----
+    // (requesting them two tiles ahead was measured neutral: 23.5 ms either way)
     float p[2][3], e[2][12];
+    int32_t r_cur[2];
 #pragma unroll
     for (int T = 0; T < 2; T++) {
         const int64_t n = base + T * 16 + s;
         const int64_t nm = n < N ? n : N - 1;        // the whole workgroup stays alive for the barriers
-        const int64_t nsrc = rows ? (int64_t)rows[nm] : nm;
+        r_cur[T] = rows ? rows[nm] : (int32_t)nm;
 #pragma unroll
-        for (int c = 0; c < 3; c++) p[T][c] = xyz_in[nsrc * 3 + c];
+        for (int c = 0; c < 3; c++) p[T][c] = xyz_in[(int64_t)r_cur[T] * 3 + c];
 #pragma unroll
         for (int m = 0; m < 5; m++) {
             const int A = m < 4 ? m * 4 + g : 16 + (g >> 1);
@@ -164,50 +211,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const floa
         }
         e[T][9] = e[T][10] = e[T][11] = 0.0f;
     }
-    __syncthreads();
-
-    // ---- weight stream: chunk c lives in ring slot c & 3 ----
-    const f32x4 *stream = reinterpret_cast<const f32x4 *>(pk);
-    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) f32x4 *)ring;
-    auto issue1 = [&](int c, int f) {      // 1 KiB fragment f of this wave's share of chunk c
-        const int frag = wave * kFrags + f;
-        unsigned keep;      // M0 carries the wave-uniform LDS destination; lane i lands at +16 i
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(lane * 16), "s"(stream + (size_t)c * kChunkF4 + frag * 64),
-                       "s"(ring_lds + (unsigned)(((c & (kRingSlots - 1)) * kChunkF4 + frag * 64) * 16))
-                     : "memory");
-    };
-    auto issue = [&](int c) {
-#pragma unroll
-        for (int f = 0; f < kFrags; f++) issue1(c, f);
-    };
-    int c = 0;                     // next chunk to enter
-    issue(0);
-    issue(1);
-    issue(2);
-
-    // Enter chunk c (3 chunks x kFrags DMAs outstanding; vmcnt(2*kFrags) retires the oldest), rendezvous; after
-    // the barrier every wave has finished reading chunk c-1, whose slot the following step refills.
-    const f32x4 *slot_;
-#define NR16_ENTER()                                                   \
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");        \
-    __builtin_amdgcn_s_barrier();                                      \
-    slot_ = ring + (c & (kRingSlots - 1)) * kChunkF4;                  \
-    c++;
-#define NR16_READ_HALF(W, HALF)                                        \
-    _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) W[ob_] = slot_[((HALF) * 4 + ob_) * 64 + lane];
-
-    f32x4 wA[4];
-    NR16_ENTER()
-    issue(3);
-    NR16_READ_HALF(wA, 0)
-
 #define NR16_HALF(W, HH, CL, KS, BOP)                                                            \
     _Pragma("unroll") for (int rr_ = 0; rr_ < 4; rr_++) {                                        \
         const int t_ = (CL) * 4 + rr_;                                                           \
-        if ((HH) == 1 && rr_ < kFrags) issue1(c + 2, rr_);                                       \
+        if ((HH) == 1 && rr_ < kFrags) {                                                         \
+            issue1(c + 2, ci, rr_);                                                              \
+            if (rr_ == kFrags - 1) ci = ci + 1 == kChunks ? 0 : ci + 1;                          \
+        }                                                                                        \
         if (t_ < (KS)) {                                                                         \
             _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) {                                \
                 _Pragma("unroll") for (int T_ = 0; T_ < 2; T_++)                                 \
@@ -258,8 +268,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const floa
         NR16_LAYER(kC_H, kKS_H, BOP_A)
         NR16_RELU()
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail chunks: nobody computes with them
-
 #pragma unroll
     for (int T = 0; T < 2; T++) {
         float off[3];
@@ -278,11 +286,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const floa
         }
         const int64_t n = base + T * 16 + s;
         if (g == 0 && n < N) {
-            const int64_t nd = rows ? (int64_t)rows[n] : n;
+            const int64_t nd = r_cur[T];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) xyz_out[nd * 3 + ch] = __fadd_rn(p[T][ch], off[ch]);
         }
     }
+    }       // tiles
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunks still in flight: nobody computes with them
 #undef BOP_E
 #undef BOP_A
 #undef BOP_SKIP
@@ -327,8 +337,8 @@ int nr_lds_launch(const float *xyz_in, int64_t N, const int32_t *rows, const int
     Params prm;
     for (int i = 0; i < 6; i++) prm.hann[i] = h_hann[i];
     const int64_t per_block = 32 * kWaves;
-    const int64_t blocks = (N + per_block - 1) / per_block;
-    OCC_REQUIRE(blocks < (1ll << 31), "nonrigid: N too large");
+    int64_t blocks = (N + per_block - 1) / per_block;
+    if (blocks > 2 * (int64_t)kNumCU) blocks = 2 * (int64_t)kNumCU;         // persistent: 2 workgroups per CU
     hipLaunchKernelGGL(nr16::nonrigid_lds_kernel, dim3((unsigned)blocks), dim3(64 * kWaves), 0, st, xyz_in, N, rows,
                        n_dev, packed, prm, xyz_out);
     return check_launch("nonrigid");
