@@ -9,11 +9,13 @@ groups=(
  "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM"
  "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL"
  "SQ_IFETCH SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS"
+ "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
+ "SQ_IFETCH_LEVEL SQ_INST_LEVEL_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES"
 )
 i=0
 for g in "${groups[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $g --output-format csv -d "$out/pass$i" -o p -- python3 "$@" > "$out/pass$i.log" 2>&1
+  timeout -k 5 120 rocprofv3 --pmc $g --output-format csv -d "$out/pass$i" -o p -- python3 "$@" > "$out/pass$i.log" 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
