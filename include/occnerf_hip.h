@@ -180,12 +180,16 @@ int occnerf_msknn(const float *xyz, int64_t N, const float *points, const int32_
  * cluster_ranges[nscale-1,ncl,2] row ranges into points; cluster_radius[nscale-1,ncl] >=
  * max |p - center| per cluster.  mask (nullable) [n_rays * samples_per_ray]: samples whose mask is
  * exactly 0 (motion-weight sum, network.py:330: their alpha is multiplied by it) are skipped and their
- * knn_idxs rows left unwritten. */
+ * knn_idxs rows left unwritten.  query_rows / n_query_dev / ray_start (nullable, together, instead of mask): the ascending
+ * list of the samples to query (occnerf_live_rows or the heads of occnerf_repeat_heads) with its length in device memory and
+ * an int32[n_rays + 1] scratch; a lane then takes the next four LISTED samples of its ray instead of four fixed sample slots,
+ * so tiles are full wherever their rays still have listed samples. */
 int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t n_rays, int32_t samples_per_ray,
                             const float *points, const float *centers,
                             const int32_t *cluster_ranges, const float *cluster_radius, int32_t ncl,
                             const int32_t *h_coarse_rows, const int32_t *h_seed_from_coarser,
-                            int32_t nscale, int32_t *knn_idxs, void *stream);
+                            int32_t nscale, const int32_t *query_rows, const int32_t *n_query_dev, int32_t *ray_start,
+                            int32_t *knn_idxs, void *stream);
 
 /* Plain exact kNN for small problems (k <= 16): idx[nq,k] rows of s, ascending.
  * Used for the per-point k=3 search of network.py:265-269 and the k=10 visibility update

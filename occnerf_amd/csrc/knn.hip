@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     const float *__restrict__ xyz, const float *__restrict__ mask /*nullable*/, int64_t n_rays, int S,
     const float4 *__restrict__ points, const float4 *__restrict__ centers,
     const int2 *__restrict__ ranges /*[nscale-1][ncl]*/, const float *__restrict__ radius /*[nscale-1][ncl]*/,
-    ClusteredScales sc, int32_t *__restrict__ knn_idxs, unsigned *__restrict__ ticket) {
+    ClusteredScales sc, int32_t *__restrict__ knn_idxs, unsigned *__restrict__ ticket,
+    const int32_t *__restrict__ qrows /*nullable: ascending list of the samples to query*/,
+    const int32_t *__restrict__ ray_start /*with qrows: [n_rays + 1] first list entry of every ray*/) {
     const int lane = threadIdx.x & 63;
     const int tiles_per_chunk = (S + 3) / 4;
     const int64_t n_tiles = ((n_rays + 63) / 64) * tiles_per_chunk;
@@ -228,12 +230,26 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
         int64_t qi[kQ];
         bool live[kQ];
         f32x2 qx[2], qy[2], qz[2];
+        // With a query list the lane's 4 queries are the NEXT FOUR LISTED samples of its ray (entries ray_start[ray] + s0 ..),
+        // not 4 fixed sample slots: a tile is full wherever its rays still have listed samples, and the tiles beyond a ray
+        // block's longest list are skipped.  (The arithmetic is this kernel's bound -- VALU 84 % busy -- and a lane evaluates
+        // its four packed distances whether the queries are listed or not.)
+        int32_t hs = 0, hn = 0;
+        if (qrows) {
+            const int64_t r = ray < n_rays ? ray : n_rays - 1;
+            hs = ray_start[r];
+            hn = ray < n_rays ? ray_start[r + 1] - hs : 0;
+        }
 #pragma unroll
         for (int a = 0; a < kQ; a++) {
             live[a] = ray < n_rays && (s0 + a) < S;
             const int64_t r = ray < n_rays ? ray : n_rays - 1;
             const int sm = (s0 + a) < S ? (s0 + a) : S - 1;
             qi[a] = r * S + sm;
+            if (qrows) {
+                live[a] = (s0 + a) < hn;
+                qi[a] = live[a] ? (int64_t)qrows[hs + s0 + a] : r * S;
+            }
             // samples whose motion-weight sum is exactly 0 cannot contribute to the pixel (their alpha is
             // multiplied by it, network.py:330): their neighbours are never read
             if (mask && mask[qi[a]] == 0.0f) live[a] = false;
@@ -451,15 +467,38 @@ OCC_API int occnerf_msknn(const float *xyz, int64_t N, const float *points,
     return check_launch("msknn");
 }
 
+namespace occ {
+// ray_start[r] = first entry of the ascending sample list that belongs to ray r or a later one (entry = sample index,
+// ray = index / S); ray_start[n_rays] = the list's length.
+__global__ void ray_list_ranges_kernel(const int32_t *__restrict__ qrows, const int32_t *__restrict__ n_dev, int64_t n_rays,
+                                       int S, int32_t *__restrict__ ray_start) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rays) return;
+    const int32_t n = *n_dev;
+    const int64_t key = r * S;
+    int32_t lo = 0, hi = n;                 // first entry >= key
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if ((int64_t)qrows[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    ray_start[r] = lo;
+}
+}  // namespace occ
+
 OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t n_rays, int32_t samples_per_ray,
                                     const float *points,
                                     const float *centers, const int32_t *cluster_ranges,
                                     const float *cluster_radius, int32_t ncl,
                                     const int32_t *h_coarse_rows,
                                     const int32_t *h_seed_from_coarser, int32_t nscale,
+                                    const int32_t *query_rows, const int32_t *n_query_dev, int32_t *ray_start,
                                     int32_t *knn_idxs, void *stream) {
     using namespace occ;
     if (n_rays <= 0 || samples_per_ray <= 0) return 0;
+    OCC_REQUIRE((!query_rows && !n_query_dev && !ray_start) || (query_rows && n_query_dev && ray_start),
+                "msknn_clustered: query_rows, n_query_dev and the ray_start scratch come together");
+    OCC_REQUIRE(!(query_rows && mask), "msknn_clustered: a query list replaces the mask");
     OCC_REQUIRE(xyz && points && centers && cluster_ranges && cluster_radius && h_coarse_rows && knn_idxs,
                 "msknn_clustered: null argument");
     OCC_REQUIRE(nscale >= 2 && nscale <= 4, "msknn_clustered: nscale=%d unsupported (2..4)", nscale);
@@ -491,10 +530,13 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t
         ticket = ring[dev] + (next[dev]++ & 63);
     }
     OCC_REQUIRE(hipMemsetAsync(ticket, 0, sizeof(unsigned), as_stream(stream)) == hipSuccess, "msknn_clustered: memset");
+    if (query_rows)
+        hipLaunchKernelGGL(ray_list_ranges_kernel, dim3((unsigned)((n_rays + 256) / 256)), dim3(256), 0, as_stream(stream),
+                           query_rows, n_query_dev, n_rays, samples_per_ray, ray_start);
     hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, mask,
                        n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points),
                        reinterpret_cast<const float4 *>(centers), reinterpret_cast<const int2 *>(cluster_ranges),
-                       cluster_radius, sc, knn_idxs, ticket);
+                       cluster_radius, sc, knn_idxs, ticket, query_rows, ray_start);
     return check_launch("msknn_clustered");
 }
 

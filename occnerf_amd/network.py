@@ -266,9 +266,13 @@ class Network(nn.Module):
             if not cfg.ignore_non_rigid_motions:
                 ops.nonrigid_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
             if dedup:       # (the positions before the offset differ in their last bits; after it they coincide)
-                scan_a, frows, fcount, kmask = ops.repeat_heads(xyz, 3, count, rows=rows, want_mask=True)
+                scan_a, frows, fcount, kmask = ops.repeat_heads(xyz, 3, count, rows=rows,
+                                                                want_mask=not cfg.get('knn_query_list', True))
             self.last_head_counts = (fcount, None)
-            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=kmask)
+            if cfg.get('knn_query_list', True):    # tiles formed over the listed samples only (same indices, tested)
+                knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], rows=frows, count=fcount)
+            else:
+                knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=kmask)
             mlp_in, raw_c, _ = ops.sample_features(
                 xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
                 self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],

@@ -346,19 +346,24 @@ def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
     return out
 
 
-def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser, mask=None):
+def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser, mask=None, rows=None, count=None):
     """cl: device-side cluster layout (dict, see Network._context / geometry.build_knn_clusters).
-    mask[n_rays*S] (optional): samples with mask == 0 are skipped, their output rows left unwritten."""
+    mask[n_rays*S] (optional): samples with mask == 0 are skipped, their output rows left unwritten.
+    rows / count (optional, instead of mask): ascending int32 list of the samples to query and its length on the device."""
     nscale = int(cl['ranges'].shape[0]) + 1
     out = torch.empty(n_rays * S, nscale, 10, device=xyz.device, dtype=torch.int32)
+    if (rows is None) != (count is None) or (rows is not None and mask is not None):
+        raise RuntimeError('msknn_clustered: rows and count come together, instead of mask')
+    ray_start = torch.empty(n_rays + 1, device=xyz.device, dtype=torch.int32) if rows is not None else None
     _kc, pc = _host_i32(cl['coarse_rows'])
     _ks, ps = _host_i32(seed_from_coarser)
     with _guard(xyz):
         rc = _lib.lib().occnerf_msknn_clustered(
             _chk(xyz, torch.float32, 'xyz'), _opt(mask, torch.float32, 'mask'), int(n_rays), int(S),
             _chk(cl['points'], torch.float32, 'points'), _chk(cl['centers'], torch.float32, 'centers'), _chk(cl['ranges'], torch.int32, 'cluster_ranges'),
-            _chk(cl['radius'], torch.float32, 'cluster_radius'), int(cl['ncl']), pc, ps, nscale, out.data_ptr(),
-            _stream(xyz))
+            _chk(cl['radius'], torch.float32, 'cluster_radius'), int(cl['ncl']), pc, ps, nscale,
+            _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'),
+            None if ray_start is None else ray_start.data_ptr(), out.data_ptr(), _stream(xyz))
     _lib.check(rc, 'msknn_clustered')
     return out
 

@@ -275,6 +275,34 @@ def test_msknn_clustered_bit_exact(case, ops):
     same(gotg, g['cnl.knn_idxs'].astype(np.int32), 'clustered knn vs reference golden')
 
 
+def test_msknn_clustered_query_list(ops):
+    """Query-list mode (tiles formed over the listed samples of each ray) == mask mode, index for index, on every listed
+    sample: ragged lists (rays with 0, 1, S listed samples), a count below the list's capacity, a ray count that is not a
+    multiple of 64."""
+    ctx = util.model_context(0, False)
+    cl = _clusters(ctx)
+    n_rays, S = 150, 23
+    g = torch.Generator(device='cpu').manual_seed(11)
+    q = ((torch.rand(n_rays * S, 3, generator=g) - 0.5) * 1.6).to(DEV)
+    keep = torch.rand(n_rays, S, generator=g) < 0.4
+    keep[3] = False
+    keep[4] = True
+    keep[5] = False
+    keep[5, 7] = True
+    keep[n_rays - 1] = True
+    mask = keep.reshape(-1).float().to(DEV)
+    rows, count = ops.live_rows(mask)
+    want = ops.msknn_clustered(q, n_rays, S, cl, [1, 1, 1, 0], mask=mask)
+    got = ops.msknn_clustered(q, n_rays, S, cl, [1, 1, 1, 0], rows=rows, count=count)
+    sel = rows[:int(count)].long()
+    assert sel.numel() > 500 and torch.equal(got[sel], want[sel])
+    # a shorter count: only the first entries are queried, and they still agree
+    short = torch.tensor([int(count) // 3], device=DEV, dtype=torch.int32)
+    got2 = ops.msknn_clustered(q, n_rays, S, cl, [1, 1, 1, 0], rows=rows, count=short)
+    sel2 = rows[:int(short)].long()
+    assert torch.equal(got2[sel2], want[sel2])
+
+
 def test_msknn_clustered_edge_cases(ops, oracle):
     ctx = util.model_context(0, False)
     cl = _clusters(ctx)

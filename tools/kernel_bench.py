@@ -106,9 +106,9 @@ def bench_knn():
     grabbed = {}
     real = ops.msknn_clustered
 
-    def grab(xyz, n_rays, S, cl, seed, mask=None):
-        grabbed.update(xyz=xyz.clone(), n=n_rays, S=S, cl=cl, seed=seed, mask=mask)
-        return real(xyz, n_rays, S, cl, seed, mask=mask)
+    def grab(xyz, n_rays, S, cl, seed, mask=None, **kw):
+        grabbed.update(xyz=xyz.clone(), n=n_rays, S=S, cl=cl, seed=seed, mask=mask, kw=kw)
+        return real(xyz, n_rays, S, cl, seed, mask=mask, **kw)
     ops.msknn_clustered = grab
     with torch.no_grad():
         net(**data, iter_val=1e7)
@@ -122,6 +122,14 @@ def bench_knn():
     if grabbed['mask'] is not None:
         tm = timeit(lambda: ops.msknn_clustered(x, n, S, cl, seed, mask=grabbed['mask']))
         print(f'msknn clustered, dead samples skipped : {tm:8.2f} ms')
+    if grabbed['kw'].get('rows') is not None:
+        tm = timeit(lambda: ops.msknn_clustered(x, n, S, cl, seed, **grabbed['kw']))
+        print(f'msknn clustered, query list           : {tm:8.2f} ms')
+        from occnerf_amd import ops as _o
+        m = torch.zeros(x.shape[0], device=x.device)
+        m[grabbed['kw']['rows'][:int(grabbed['kw']['count'])].long()] = 1.0
+        tm = timeit(lambda: ops.msknn_clustered(x, n, S, cl, seed, mask=m))
+        print(f'msknn clustered, same samples by mask : {tm:8.2f} ms')
 
 
 def bench_stage(name):
