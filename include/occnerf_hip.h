@@ -287,6 +287,17 @@ int64_t occnerf_repeat_heads_temp_bytes(int64_t N_max);
 int occnerf_repeat_heads(const void *keys, int64_t stride_dwords, int32_t key_dwords, const int32_t *rows,
                          const int32_t *n_dev, int64_t N_max, int32_t *scan, int32_t *heads, int32_t *head_count,
                          float *head_mask, void *temp, int64_t temp_bytes, void *stream);
+/* Distinct entries of a whole list (what run-length elimination leaves: equal keys that are not neighbours).  Entry j < *n_dev
+ * is row r = heads ? heads[j] : j with the key of occnerf_repeat_heads; entries are grouped by an open-addressing table
+ * (atomicCAS on a slot, full-key compare against the claimant), heads_out / *count_out list one representative row per
+ * distinct key in ascending entry order, and scan (nullable, with its device-side length and capacity) -- a map whose
+ * values are 1-based entry numbers, e.g. occnerf_repeat_heads' scan -- is rewritten to 1-based positions in heads_out.  Which
+ * of several equal entries represents them is not deterministic; since their keys are equal bit for bit, results are.
+ * temp = device scratch of occnerf_unique_heads_temp_bytes(cap) bytes; cap = capacity of the list. */
+int64_t occnerf_unique_heads_temp_bytes(int64_t cap);
+int occnerf_unique_heads(const void *keys, int64_t stride_dwords, int32_t key_dwords, const int32_t *heads,
+                         const int32_t *n_dev, int64_t cap, int32_t *heads_out, int32_t *count_out, int32_t *scan,
+                         const int32_t *n_scan_dev, int64_t scan_cap, void *temp, int64_t temp_bytes, void *stream);
 int occnerf_scatter_raw_heads(const float *raw_h, const float *raw_c, const int32_t *rows, const int32_t *n_dev,
                               const int32_t *scanA, const int32_t *scanB, int64_t N_max, float *raw_full, void *stream);
 int occnerf_canonical_mlp_rows(const float *mlp_in, const int32_t *in_rows, int64_t N_max, const int32_t *n_dev,

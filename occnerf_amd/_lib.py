@@ -49,6 +49,8 @@ SIGNATURES = {
     'occnerf_scatter_raw': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     'occnerf_repeat_heads_temp_bytes': (_i64, [_i64]),
     'occnerf_repeat_heads': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'occnerf_unique_heads_temp_bytes': (_i64, [_i64]),
+    'occnerf_unique_heads': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     'occnerf_scatter_raw_heads': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'occnerf_canonical_mlp_rows': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp_counted': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),

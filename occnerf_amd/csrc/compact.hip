@@ -116,6 +116,88 @@ __global__ void scatter_raw_heads_kernel(const float *__restrict__ raw_h, const 
     raw_full[n * 5 + 4] = raw_c[a * 5 + 4];
 }
 
+// ---- distinct samples across the whole list ------------------------------------------------------------------
+// Run-length elimination leaves the repeats that are not neighbours in the list (collapsed samples of different rays).
+// occnerf_unique_heads finds them with an open-addressing table of list positions: an entry hashes its key, claims the
+// first free slot of its probe sequence with one atomicCAS or meets an earlier claimant there, compares the FULL keys as bit
+// patterns and, if they are equal, takes that entry as its representative.  Which of several equal entries wins the slot is
+// a race, and does not matter: equal keys give equal results, so the pixels do not depend on the winner; the NUMBER of
+// representatives is the number of distinct keys (an entry whose 32 probes all meet other keys stays its own
+// representative -- exact, merely one row more).
+__device__ __forceinline__ uint64_t mix64(uint64_t h) {
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    return h;
+}
+
+template <int G /* lanes per entry: 1 for narrow keys, 8 for rows */>
+__global__ void unique_insert_kernel(const uint32_t *__restrict__ keys, int64_t stride, int K,
+                                     const int32_t *__restrict__ heads, const int32_t *__restrict__ n_dev,
+                                     int32_t *__restrict__ table, uint32_t tmask, int32_t *__restrict__ rep) {
+    const int g = threadIdx.x % G;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (j >= (int64_t)*n_dev) return;                       // (whole groups leave together)
+    const uint32_t *a = keys + (heads ? (int64_t)heads[j] : j) * stride;
+    uint64_t h = 0x9E3779B97F4A7C15ull * (uint64_t)(g + 1);
+    for (int k = g; k < K; k += G) h = mix64(h ^ ((uint64_t)a[k] + ((uint64_t)(k + 1) << 32)));
+    if (G > 1) {
+        h ^= __shfl_xor(h, 1, G);
+        h ^= __shfl_xor(h, 2, G);
+        h ^= __shfl_xor(h, 4, G);
+    }
+    uint32_t slot = (uint32_t)mix64(h) & tmask;
+    int32_t r = (int32_t)j;
+    for (int probe = 0; probe < 32; probe++) {
+        int32_t prev = 0;
+        if (g == 0) prev = atomicCAS(&table[slot], -1, (int32_t)j);
+        if (G > 1) prev = __shfl(prev, 0, G);
+        if (prev == -1) break;                              // claimed: its own representative
+        const uint32_t *b = keys + (heads ? (int64_t)heads[prev] : (int64_t)prev) * stride;
+        int diff = 0;
+        for (int k = g; k < K; k += G) diff |= a[k] != b[k];
+        if (G > 1) {
+            diff |= __shfl_xor(diff, 1, G);
+            diff |= __shfl_xor(diff, 2, G);
+            diff |= __shfl_xor(diff, 4, G);
+        }
+        if (!diff) {
+            r = prev;
+            break;
+        }
+        slot = (slot + 1) & tmask;
+    }
+    if (g == 0) rep[j] = r;
+}
+
+struct IsRepresentative {
+    const int32_t *rep, *n_dev;
+    __device__ int operator()(const int &j) const { return j < *n_dev && rep[j] == j; }
+};
+
+// heads_out[scan2[j]-1] = row of representative j; rep[j] <- position of j's representative in heads_out; *count_out
+__global__ void unique_finish_kernel(const int32_t *__restrict__ heads, const int32_t *__restrict__ n_dev,
+                                     const int32_t *__restrict__ scan2, int32_t *__restrict__ rep,
+                                     int32_t *__restrict__ heads_out, int32_t *__restrict__ count_out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = *n_dev;
+    if (j == 0 && n <= 0) *count_out = 0;
+    if (j >= n) return;
+    const int32_t r = rep[j];
+    if (r == (int32_t)j) heads_out[scan2[j] - 1] = heads ? heads[j] : (int32_t)j;
+    if (j == n - 1) *count_out = scan2[j];
+    rep[j] = scan2[r] - 1;          // (reads rep of no other entry: in place)
+}
+
+__global__ void unique_remap_kernel(int32_t *__restrict__ scan, const int32_t *__restrict__ n_scan_dev,
+                                    const int32_t *__restrict__ pos) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= (int64_t)*n_scan_dev) return;
+    scan[m] = pos[scan[m] - 1] + 1;
+}
+
 }  // namespace occ
 
 OCC_API int64_t occnerf_repeat_heads_temp_bytes(int64_t N) {
@@ -160,6 +242,61 @@ OCC_API int occnerf_repeat_heads(const void *keys, int64_t stride_dwords, int32_
     hipLaunchKernelGGL(repeat_heads_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), scan, rows, n_dev,
                        heads, head_count, head_mask);
     return check_launch("repeat_heads");
+}
+
+static inline int64_t unique_table_entries(int64_t cap) {
+    int64_t t = 1024;
+    while (t < cap) t <<= 1;
+    return t;
+}
+
+OCC_API int64_t occnerf_unique_heads_temp_bytes(int64_t cap) {
+    using namespace occ;
+    if (cap <= 0 || cap >= (1ll << 30)) return 0;
+    size_t bytes = 0;
+    hipcub::CountingInputIterator<int> it(0);
+    hipcub::TransformInputIterator<int, IsRepresentative, hipcub::CountingInputIterator<int>> flags(it, IsRepresentative{});
+    if (hipcub::DeviceScan::InclusiveSum(nullptr, bytes, flags, (int *)nullptr, (int)cap, (hipStream_t)0) != hipSuccess)
+        return -1;
+    const int64_t words = unique_table_entries(cap) + 2 * ((cap + 63) & ~63ll);
+    return words * 4 + (int64_t)((bytes + 255) & ~(size_t)255);
+}
+
+OCC_API int occnerf_unique_heads(const void *keys, int64_t stride_dwords, int32_t key_dwords, const int32_t *heads,
+                                 const int32_t *n_dev, int64_t cap, int32_t *heads_out, int32_t *count_out,
+                                 int32_t *scan, const int32_t *n_scan_dev, int64_t scan_cap, void *temp,
+                                 int64_t temp_bytes, void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(keys && n_dev && heads_out && count_out && temp, "unique_heads: null argument");
+    OCC_REQUIRE(cap > 0 && cap < (1ll << 30), "unique_heads: cap=%lld out of range", (long long)cap);
+    OCC_REQUIRE(key_dwords > 0 && stride_dwords >= key_dwords, "unique_heads: key of %d dwords in rows of %lld", key_dwords,
+                (long long)stride_dwords);
+    OCC_REQUIRE(!scan == !n_scan_dev, "unique_heads: scan and its length come together");
+    OCC_REQUIRE(temp_bytes >= occnerf_unique_heads_temp_bytes(cap), "unique_heads: temp too small");
+    const int64_t T = unique_table_entries(cap), capr = (cap + 63) & ~63ll;
+    int32_t *table = reinterpret_cast<int32_t *>(temp), *rep = table + T, *scan2 = rep + capr;
+    void *cub_temp = scan2 + capr;
+    size_t cub_bytes = (size_t)temp_bytes - (size_t)(T + 2 * capr) * 4;
+    hipStream_t st = as_stream(stream);
+    OCC_REQUIRE(hipMemsetAsync(table, 0xFF, (size_t)T * 4, st) == hipSuccess, "unique_heads: memset");
+    const uint32_t *k32 = reinterpret_cast<const uint32_t *>(keys);
+    if (key_dwords >= 32)
+        hipLaunchKernelGGL(unique_insert_kernel<8>, dim3((unsigned)((cap * 8 + 255) / 256)), dim3(256), 0, st, k32,
+                           stride_dwords, key_dwords, heads, n_dev, table, (uint32_t)(T - 1), rep);
+    else
+        hipLaunchKernelGGL(unique_insert_kernel<1>, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, k32,
+                           stride_dwords, key_dwords, heads, n_dev, table, (uint32_t)(T - 1), rep);
+    hipcub::CountingInputIterator<int> it(0);
+    hipcub::TransformInputIterator<int, IsRepresentative, hipcub::CountingInputIterator<int>> flags(
+        it, IsRepresentative{rep, n_dev});
+    const hipError_t e = hipcub::DeviceScan::InclusiveSum(cub_temp, cub_bytes, flags, scan2, (int)cap, st);
+    OCC_REQUIRE(e == hipSuccess, "unique_heads: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(unique_finish_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, heads, n_dev, scan2, rep,
+                       heads_out, count_out);
+    if (scan)
+        hipLaunchKernelGGL(unique_remap_kernel, dim3((unsigned)((scan_cap + 255) / 256)), dim3(256), 0, st, scan, n_scan_dev,
+                           rep);
+    return check_launch("unique_heads");
 }
 
 OCC_API int occnerf_scatter_raw_heads(const float *raw_h, const float *raw_c, const int32_t *rows, const int32_t *n_dev,

@@ -268,6 +268,10 @@ class Network(nn.Module):
             if dedup:       # (the positions before the offset differ in their last bits; after it they coincide)
                 scan_a, frows, fcount, kmask = ops.repeat_heads(xyz, 3, count, rows=rows,
                                                                 want_mask=not cfg.get('knn_query_list', True))
+                # (the positions' repeats that are not neighbours in the list are few -- 9.28 M -> 8.39 M on the benchmark
+                # frame -- and finding them, 1.7 ms, costs more than the kNN + feature work they save, 0.6 ms)
+                if cfg.get('dedup_global_positions', False):
+                    frows, fcount = ops.unique_heads(xyz, 3, frows, fcount, scan=scan_a, scan_count=count)
             self.last_head_counts = (fcount, None)
             if cfg.get('knn_query_list', True):    # tiles formed over the listed samples only (same indices, tested)
                 knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], rows=frows, count=fcount)
@@ -281,6 +285,8 @@ class Network(nn.Module):
             del knn
             if dedup:
                 scan_b, mrows, mcount, _ = ops.repeat_heads(mlp_in, 68, fcount)
+                if cfg.get('dedup_global', True):       # ... and the repeats that are not neighbours in the list
+                    mrows, mcount = ops.unique_heads(mlp_in, 68, mrows, mcount, scan=scan_b, scan_count=fcount)
                 self.last_head_counts = (fcount, mcount)
                 raw_h = torch.empty(mlp_in.shape[0], 5, device=dev)
                 ops.canonical_mlp(mlp_in, pk['cnl'], raw_h, count=mcount, in_rows=mrows)

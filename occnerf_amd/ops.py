@@ -299,6 +299,33 @@ def repeat_heads(keys, key_cols, count, rows=None, want_mask=False):
     return scan, heads, head_count, head_mask
 
 
+def unique_heads(keys, key_cols, heads, count, scan=None, scan_count=None):
+    """Distinct entries of a list (see the header): heads int32[cap] (or None: entry j is row j of keys, cap = rows of
+    keys), count int32[1] on the device -> (heads_out int32[cap], count_out int32[1]); scan (optional, with scan_count) is
+    rewritten in place from 1-based entry numbers to 1-based positions in heads_out."""
+    dev = keys.device
+    if keys.dim() != 2 or not keys.is_contiguous() or keys.element_size() != 4:
+        raise RuntimeError('unique_heads: keys must be a contiguous [M, C] tensor of 4-byte elements')
+    cap = keys.shape[0] if heads is None else heads.shape[0]
+    heads_out = torch.empty(cap, device=dev, dtype=torch.int32)
+    count_out = torch.empty(1, device=dev, dtype=torch.int32)
+    if cap == 0:
+        count_out.zero_()
+        return heads_out, count_out
+    nbytes = int(_lib.lib().occnerf_unique_heads_temp_bytes(cap))
+    if nbytes <= 0:
+        raise RuntimeError('unique_heads: temp size query failed')
+    temp = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_unique_heads(
+            keys.data_ptr(), keys.shape[1], int(key_cols), _opt(heads, torch.int32, 'heads'),
+            _chk(count, torch.int32, 'count'), cap, heads_out.data_ptr(), count_out.data_ptr(),
+            _opt(scan, torch.int32, 'scan'), _opt(scan_count, torch.int32, 'scan_count'),
+            0 if scan is None else scan.shape[0], temp.data_ptr(), nbytes, _stream(keys))
+    _lib.check(rc, 'unique_heads')
+    return heads_out, count_out
+
+
 def scatter_raw_heads(raw_h, raw_c, rows, count, scan_a, scan_b, raw_full):
     with _guard(raw_c):
         rc = _lib.lib().occnerf_scatter_raw_heads(

@@ -874,6 +874,43 @@ def test_repeat_heads(ops, n, kcols, ccols):
         assert np.array_equal(full, ref)
 
 
+@pytest.mark.parametrize('n,kcols,ccols', [(1, 3, 3), (4000, 3, 3), (50000, 68, 68), (3000, 4, 8)])
+def test_unique_heads(ops, n, kcols, ccols):
+    """Distinct rows of a whole list against numpy: one representative per distinct key (bit patterns), ascending order of
+    the representatives, every entry mapped to a representative with an equal key; through a head list and a scan map."""
+    rng = np.random.default_rng(n + 1)
+    base = rng.standard_normal((max(n // 9, 1), ccols)).astype(np.float32)
+    keys = base[rng.integers(0, base.shape[0], n)].copy()              # repeats scattered over the list
+    if n > 10:
+        keys[7, 0], keys[8] = 0.0, keys[7]
+        keys[8, 0] = -0.0
+    kd = torch.from_numpy(keys).to(DEV)
+    kb = np.ascontiguousarray(keys.view(np.uint32)[:, :kcols])
+    for use_heads in (False, True):
+        if use_heads:
+            heads_np = np.sort(rng.choice(n, size=max(n * 3 // 4, 1), replace=False)).astype(np.int32)
+            heads = torch.from_numpy(heads_np).to(DEV)
+        else:
+            heads_np, heads = np.arange(n, dtype=np.int32), None
+        cnt = heads_np.shape[0] if n != 4000 else heads_np.shape[0] - 17
+        count = torch.tensor([cnt], device=DEV, dtype=torch.int32)
+        # a map onto the entries (1-based), as occnerf_repeat_heads' scan is
+        scan_np = rng.integers(1, cnt + 1, size=cnt + 5).astype(np.int32)
+        scan = torch.from_numpy(scan_np.copy()).to(DEV)
+        scan_count = torch.tensor([cnt + 3], device=DEV, dtype=torch.int32)
+        out, ocount = ops.unique_heads(kd, kcols, heads, count, scan=scan, scan_count=scan_count)
+        m = int(ocount)
+        got = out[:m].cpu().numpy()
+        ent = kb[heads_np[:cnt]]
+        assert m == np.unique(ent, axis=0).shape[0]
+        assert np.all(np.diff(np.searchsorted(heads_np[:cnt], got)) > 0)           # ascending entry order
+        assert np.unique(kb[got], axis=0).shape[0] == m                                 # all distinct
+        new_scan = scan.cpu().numpy()
+        assert np.array_equal(new_scan[cnt + 3:], scan_np[cnt + 3:])                  # beyond its length: untouched
+        mapped = got[new_scan[:cnt + 3] - 1]                                           # representative rows
+        assert np.array_equal(kb[mapped], ent[scan_np[:cnt + 3] - 1])                  # ... with the entry's key
+
+
 def test_canonical_mlp_rows(ops):
     """occnerf_canonical_mlp_rows == occnerf_canonical_mlp_counted on the gathered rows, bit for bit."""
     ctx = util.model_context(0, False)
@@ -910,7 +947,16 @@ def test_dedup_repeated_samples_is_exact(ops, size, S, amplify):
     net.cfg.dedup_repeated_samples = True
     assert 0 < heads_b <= heads_a <= live
     if size == 512:
-        assert heads_a < 0.7 * live and heads_b < 0.5 * live, (live, heads_a, heads_b)
+        assert heads_a < 0.6 * live and heads_b < 0.4 * live, (live, heads_a, heads_b)
+        for glob, gpos in ((False, False), (True, True)):   # run-length only / global on both stages: the same pixels
+            net.cfg.dedup_global, net.cfg.dedup_global_positions = glob, gpos
+            with torch.no_grad():
+                o = net(**data, iter_val=1e7)
+            ha, hb = int(net.last_head_counts[0]), int(net.last_head_counts[1])
+            assert (ha == heads_a and hb > heads_b) if not glob else (ha < heads_a and hb == heads_b), (ha, hb)
+            for k in ('rgb', 'alpha', 'depth'):
+                assert torch.equal(o[k], outs[1][k]), k
+        net.cfg.dedup_global, net.cfg.dedup_global_positions = True, False
     for k in ('rgb', 'alpha', 'depth'):
         assert torch.equal(outs[0][k], outs[1][k]), k
     assert float(outs[0]['alpha'].max()) > 0.05
