@@ -386,6 +386,31 @@ def test_sample_features_and_mlp(case, ops):
     assert np.abs(raw3.cpu().numpy()[:, :4] - ref).max() <= (5e-5 if amp else 1e-6)
 
 
+def test_sample_features_generic_level_layout(case, ops, oracle):
+    """A level layout the reference's constructor never produces -- hashed levels whose size is not a power of two (the
+    reference's loop + modulo, `GENERIC` instantiation of the 8-lanes-per-sample kernel) -- against the oracle's encoder on
+    the kernel's own encoder inputs, bit for bit; dense levels and power-of-two levels side by side in the same wave."""
+    g, ctx, o = case
+    m = _dev_model(ctx, ops)
+    off = ctx['offsets'].astype(np.int64)
+    sizes = np.diff(off)
+    sizes[3], sizes[6], sizes[15] = 300000, 123456, 500008          # multiples of 8, not powers of two, hashed
+    off2 = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    rng = np.random.default_rng(5)
+    emb2 = rng.uniform(-1, 1, (int(off2[-1]), 2)).astype(np.float32)
+    table = T(np.concatenate([o['table'], np.zeros((o['table'].shape[0], ops.table_stride() - 35), np.float32)], 1))
+    N = o['xyz'].shape[0]
+    rows = torch.arange(N, device=DEV, dtype=torch.int32)            # (a row list routes to the 8-lanes kernel)
+    count = torch.tensor([N], device=DEV, dtype=torch.int32)
+    mlp_in, raw, enc_in = ops.sample_features(T(o['xyz']), T(o['knn']), m['base'], m['normals'], m['unit'],
+                                              T(ctx['counter']), table, m['b32'], m['tb32'], T(emb2), T(off2), ctx['S'],
+                                              ctx['H'], want_enc_in=True, rows=rows, count=count)
+    x = enc_in.cpu().numpy()
+    want, _ = oracle.grid_encode_forward(x, emb2, off2, ctx['S'], ctx['H'])               # [L, B, C]
+    same(mlp_in.cpu().numpy()[:, 36:], want.transpose(1, 0, 2).reshape(N, -1), 'hash encoding, generic level layout')
+    same(raw.cpu().numpy()[:, 4], o['raw'][:, 4], 'signed distance')
+
+
 @pytest.mark.parametrize('n', [1, 15, 16, 17, 63, 64, 65, 1000, 4097])
 def test_canonical_mlp_ragged(ops, n):
     """Workgroups of 4 waves x 16 samples: partial waves, partial workgroups, column 4 untouched."""
