@@ -240,6 +240,70 @@ __global__ __launch_bounds__(kWaves * 64, 2) void k_two_tiles(const float *__res
     if (s == 12345.678f) out[0] = s;
 }
 
+// mode 7: one 16-sample tile per wave at width 128 (8 accumulators), 8 KiB chunks = 32 MFMAs per wave (8 ds_read_b128, 2 DMA
+// fragments, 1 barrier per 32 MFMAs), FOUR waves per SIMD (4 workgroups of 4 waves per CU).
+__global__ __launch_bounds__(kWaves * 64, 4) void k_one_tile_w128(const float *__restrict__ pk, int groups, float *out) {
+    constexpr int kChunk8 = 512;
+    __shared__ __attribute__((aligned(16))) f32x4 ring[kSlots * kChunk8];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < kSlots * kChunk8; i += kWaves * 64) ring[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f};
+    __syncthreads();
+    f32x4 acc[8], act[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        acc[i] = f32x4{0, 0, 0, 0};
+        act[i] = f32x4{lane * 1e-3f, 1.f, 2.f, 3.f};
+    }
+    const f32x4 *stream = reinterpret_cast<const f32x4 *>(pk);
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) f32x4 *)ring;
+    auto issue1 = [&](int c, int f) {
+        const int frag = wave * 2 + f;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane * 16), "s"(stream + (size_t)(c & 63) * kChunk8 + frag * 64),
+                       "s"(ring_lds + (unsigned)(((c & (kSlots - 1)) * kChunk8 + frag * 64) * 16))
+                     : "memory");
+    };
+    int c = 0;
+    for (int j = 0; j < 3; j++)
+        for (int f = 0; f < 2; f++) issue1(j, f);
+    f32x4 wA[4], wB[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) wA[i] = wB[i] = f32x4{1e-3f, 2e-3f, 1e-3f, 2e-3f};
+    const f32x4 *slot = ring;
+#pragma unroll 1
+    for (int gi = 0; gi < groups; gi++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) wB[i] = slot[(4 + i) * 64 + lane];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+            for (int ob = 0; ob < 4; ob++)
+                acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ob][rr], act[gi & 7][rr], acc[ob], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        slot = ring + (c & (kSlots - 1)) * kChunk8;
+        c++;
+#pragma unroll
+        for (int i = 0; i < 4; i++) wA[i] = slot[i * 64 + lane];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            if (rr < 2) issue1(c + 2, rr);
+#pragma unroll
+            for (int ob = 0; ob < 4; ob++)
+                acc[4 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[ob][rr], act[gi & 7][rr], acc[4 + ob], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + act[i][0];
+    if (s == 12345.678f) out[0] = s;
+}
+
 template <int MODE, int W>
 static void run(const float *pk, float *out, const char *what) {
     const int groups = 2048, blocks = 256 * W * 8;
@@ -304,6 +368,23 @@ int main() {
         const double tf = (double)blocks * kWaves * groups * 64 * 2.0 * 16 * 16 * 4 / (ms * 1e-3) / 1e12;
         printf("mode 6, 2 wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3\n",
                "two tiles per wave: 8 ds_read, 2 DMA, 1 barrier per 64 MFMAs", ms, tf, tf / 157.3);
+    }
+    {
+        const int groups = 4096, blocks = 256 * 4 * 8;
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        float ms = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(k_one_tile_w128, dim3(blocks), dim3(kWaves * 64), 0, 0, pk, groups, out);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
+        }
+        const double tf = (double)blocks * kWaves * groups * 32 * 2.0 * 16 * 16 * 4 / (ms * 1e-3) / 1e12;
+        printf("mode 7, 4 wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3\n",
+               "one tile, width 128: 8 ds_read, 2 DMA, 1 barrier per 32 MFMAs", ms, tf, tf / 157.3);
     }
     return 0;
 }
