@@ -14,6 +14,16 @@
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// shader clock held during a kernel: block 0 / lane 0 reads the shader-cycle counter and the constant 100 MHz counter at its
+// start and end
+__device__ unsigned long long g_clk[4];
+#define CLK_BEGIN() if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = clock64(); g_clk[1] = wall_clock64(); }
+#define CLK_END() if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[2] = clock64(); g_clk[3] = wall_clock64(); }
+static double held_ghz() {
+    unsigned long long h[4];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk), sizeof(h));
+    return (double)(h[2] - h[0]) / ((double)(h[3] - h[1]) * 10.0);      // cycles per 10 ns tick -> GHz
+}
 constexpr int kWaves = 4, kSlots = 4, kChunkF4 = 1024;      // 16 KiB chunks, 4-slot ring
 
 template <int MODE, int WAVES_PER_SIMD>
@@ -24,6 +34,7 @@ __global__ __launch_bounds__(kWaves * 64, WAVES_PER_SIMD) void k(const float *__
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < kSlots * kChunkF4; i += kWaves * 64) ring[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f};
     __syncthreads();
+    CLK_BEGIN()
     f32x4 acc[16], act[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -88,6 +99,7 @@ __global__ __launch_bounds__(kWaves * 64, WAVES_PER_SIMD) void k(const float *__
         }
     }
     if (MODE >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLK_END()
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + act[i][0];
@@ -102,6 +114,7 @@ __global__ __launch_bounds__(5 * 64, 2) void k_loader(const float *__restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < kSlots * kChunkF4; i += 5 * 64) ring[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f};
     __syncthreads();
+    CLK_BEGIN()
     const f32x4 *stream = reinterpret_cast<const f32x4 *>(pk);
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) f32x4 *)ring;
     if (wave == 4) {        // ---- loader ----
@@ -162,6 +175,7 @@ __global__ __launch_bounds__(5 * 64, 2) void k_loader(const float *__restrict__ 
                 acc[8 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[ob][rr], act[gi & 15][rr], acc[8 + ob], 0, 0, 0);
         }
     }
+    CLK_END()
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + act[i][0];
@@ -177,6 +191,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void k_two_tiles(const float *__res
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < kSlots * kChunk8; i += kWaves * 64) ring[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f};
     __syncthreads();
+    CLK_BEGIN()
     f32x4 acc[2][8], act[2][8];
 #pragma unroll
     for (int T = 0; T < 2; T++)
@@ -232,6 +247,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void k_two_tiles(const float *__res
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLK_END()
     float s = 0;
 #pragma unroll
     for (int T = 0; T < 2; T++)
@@ -249,6 +265,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void k_one_tile_w128(const float *_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < kSlots * kChunk8; i += kWaves * 64) ring[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f};
     __syncthreads();
+    CLK_BEGIN()
     f32x4 acc[8], act[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -298,6 +315,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void k_one_tile_w128(const float *_
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLK_END()
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + act[i][0];
@@ -320,7 +338,7 @@ static void run(const float *pk, float *out, const char *what) {
     }
     const double flop = (double)blocks * kWaves * groups * 64 * 2.0 * 16 * 16 * 4;
     const double tf = flop / (ms * 1e-3) / 1e12;
-    printf("mode %d, %d wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3\n", MODE, W, what, ms, tf, tf / 157.3);
+    printf("mode %d, %d wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3  (block 0 ran at %.3f GHz)\n", MODE, W, what, ms, tf, tf / 157.3, held_ghz());
 }
 
 int main() {
@@ -349,8 +367,8 @@ int main() {
             (void)hipEventElapsedTime(&ms, e0, e1);
         }
         const double tf = (double)blocks * kWaves * groups * 64 * 2.0 * 16 * 16 * 4 / (ms * 1e-3) / 1e12;
-        printf("mode 5, 2 wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3\n",
-               "mode 3 with a fifth wave per workgroup as the only DMA issuer", ms, tf, tf / 157.3);
+        printf("mode 5, 2 wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3  (block 0 ran at %.3f GHz)\n",
+               "mode 3 with a fifth wave per workgroup as the only DMA issuer", ms, tf, tf / 157.3, held_ghz());
     }
     {
         const int groups = 2048, blocks = 256 * 2 * 8;
@@ -366,8 +384,8 @@ int main() {
             (void)hipEventElapsedTime(&ms, e0, e1);
         }
         const double tf = (double)blocks * kWaves * groups * 64 * 2.0 * 16 * 16 * 4 / (ms * 1e-3) / 1e12;
-        printf("mode 6, 2 wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3\n",
-               "two tiles per wave: 8 ds_read, 2 DMA, 1 barrier per 64 MFMAs", ms, tf, tf / 157.3);
+        printf("mode 6, 2 wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3  (block 0 ran at %.3f GHz)\n",
+               "two tiles per wave: 8 ds_read, 2 DMA, 1 barrier per 64 MFMAs", ms, tf, tf / 157.3, held_ghz());
     }
     {
         const int groups = 4096, blocks = 256 * 4 * 8;
@@ -383,8 +401,8 @@ int main() {
             (void)hipEventElapsedTime(&ms, e0, e1);
         }
         const double tf = (double)blocks * kWaves * groups * 32 * 2.0 * 16 * 16 * 4 / (ms * 1e-3) / 1e12;
-        printf("mode 7, 4 wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3\n",
-               "one tile, width 128: 8 ds_read, 2 DMA, 1 barrier per 32 MFMAs", ms, tf, tf / 157.3);
+        printf("mode 7, 4 wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3  (block 0 ran at %.3f GHz)\n",
+               "one tile, width 128: 8 ds_read, 2 DMA, 1 barrier per 32 MFMAs", ms, tf, tf / 157.3, held_ghz());
     }
     return 0;
 }
