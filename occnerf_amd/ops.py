@@ -373,12 +373,13 @@ def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
     return out
 
 
-def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser, mask=None, rows=None, count=None):
+def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser, mask=None, rows=None, count=None, out=None):
     """cl: device-side cluster layout (dict, see Network._context / geometry.build_knn_clusters).
     mask[n_rays*S] (optional): samples with mask == 0 are skipped, their output rows left unwritten.
     rows / count (optional, instead of mask): ascending int32 list of the samples to query and its length on the device."""
     nscale = int(cl['ranges'].shape[0]) + 1
-    out = torch.empty(n_rays * S, nscale, 10, device=xyz.device, dtype=torch.int32)
+    if out is None:
+        out = torch.empty(n_rays * S, nscale, 10, device=xyz.device, dtype=torch.int32)
     if (rows is None) != (count is None) or (rows is not None and mask is not None):
         raise RuntimeError('msknn_clustered: rows and count come together, instead of mask')
     ray_start = torch.empty(n_rays + 1, device=xyz.device, dtype=torch.int32) if rows is not None else None
