@@ -28,9 +28,7 @@ class SyntheticFrames:
         if self.data_type == 'tpose':
             return None
         if self.data_type == 'movement':
-            a, b = synth.seeded_pose(11), synth.seeded_pose(12)
-            t = 0.5 - 0.5 * np.cos(2 * np.pi * idx / max(self.total_frames, 1))
-            return ((1 - t) * a + t * b).astype('float32')
+            return synth.movement_pose(idx, self.total_frames)
         return synth.seeded_pose(int(cfg.freeview.get('frame_idx', 0)) + 1)
 
     def __iter__(self):

@@ -418,6 +418,14 @@ def seeded_pose(seed, sigma=0.3):
     return pose
 
 
+def movement_pose(idx, total_frames, seed_a=11, seed_b=12):
+    """Frame idx of the synthetic movement sequence: a smooth closed walk between two seeded poses (stands in for
+    the observed frames of ZJU-MoCap 387, core/data/create_dataset.py:28-33 `movement`)."""
+    a, b = seeded_pose(seed_a), seeded_pose(seed_b)
+    t = 0.5 - 0.5 * np.cos(2 * np.pi * idx / max(int(total_frames), 1))
+    return ((1 - t) * a + t * b).astype('float32')
+
+
 def posed_joints(pose72, tjoints):
     """Forward kinematics of the skeleton only (for the observation-space bbox)."""
     Rs, Ts = body_pose_to_body_RTs(pose72, tjoints)

@@ -24,7 +24,7 @@ sys.path.insert(0, REPO)
 
 from oracle.ref_harness import shims  # noqa: E402
 
-OUT_DIR = os.path.join(REPO, 'tests', 'golden')
+OUT_DIR = os.environ.get('OCCNERF_GOLDEN_DIR') or os.path.join(REPO, 'tests', 'golden')   # the reproducibility test writes elsewhere
 CASES = sys.argv[1:] or ['all']            # read before shims.install() rewrites sys.argv
 
 cfg = shims.install(['run.py', '--cfg', 'configs/occnerf/zju_mocap/387/occnerf.yaml',
@@ -380,6 +380,11 @@ if __name__ == '__main__':
     if 'all' in which or 'freeview' in which:
         run_case('freeview_amp_s32', img_size=32, S=32, amplify=True, pose=synth.seeded_pose(1),
                  orbit_frame=28, non_rigid=True, keep_rays=160)
+    if 'all' in which or 'movement' in which:        # configs[2]: two frames of the movement pose walk
+        run_case('movement_amp_s32_f3', img_size=32, S=32, amplify=True, pose=synth.movement_pose(3, 20),
+                 non_rigid=True, keep_rays=96)
+        run_case('movement_amp_s32_f9', img_size=32, S=32, amplify=True, pose=synth.movement_pose(9, 20),
+                 non_rigid=True, keep_rays=96)
     if 'all' in which or 'train' in which:
         run_train_case('train_amp_s32')
         run_train_case('train_ri_s32', amplify=False)

@@ -8,7 +8,8 @@ from occnerf_amd import checkpoint, geometry, synth
 from occnerf_amd.gridencoder import grid_offsets
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-GOLDEN_CASES = ['tpose_ri_s32', 'tpose_ri_s128', 'freeview_amp_s32', 'tpose_amp_s32']
+GOLDEN_CASES = ['tpose_ri_s32', 'tpose_ri_s128', 'freeview_amp_s32', 'tpose_amp_s32',
+                'movement_amp_s32_f3', 'movement_amp_s32_f9']
 
 
 def load_golden(name):
