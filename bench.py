@@ -54,7 +54,7 @@ TRAIN_RAYS = 6144                     # default.yaml patch config: 6 patches x 3
 def cpu_baseline(ctx, frame, n_rays):
     """rays/s of the CPU oracle on `n_rays` rays spread over the frame (rank 0, N=1 only)."""
     from oracle import oracle as orc
-    from tests.gpu_util import stagewise_oracle_render
+    from oracle.chain import stagewise_oracle_render
     orc.build()
     R = frame['rays'].shape[1]
     sel = np.linspace(0, R - 1, n_rays).astype(np.int64)
@@ -82,13 +82,6 @@ def pmc_traffic(n_samples):
         except Exception:
             pass
     return None, None
-
-
-def host_frame(frame):
-    """The frame as the dataset would hand it over: pinned host tensors; the three float[3] constants stay on the
-    host (the kernels take them by value)."""
-    from tests.gpu_util import FRAME_KEYS
-    return {k: torch.from_numpy(np.ascontiguousarray(frame[k])).pin_memory() for k in FRAME_KEYS}
 
 
 def timed_steps(renderer, frame_h, steps, warmup, rank, world, dev, order_key, host_out):
@@ -136,8 +129,8 @@ def train_leg(dev, steps, warmup):
     with bf16 MLP trunks, gradient clipping and Adam on the device."""
     from occnerf_amd import synth
     from occnerf_amd.optim import FusedAdam
-    from tests.gpu_util import build_network, frame_to_device
-    net, _ = build_network(seed=0, amplify=False, S=SPP, non_rigid=True, device=dev)
+    from occnerf_amd.seeded import build_network, frame_to_device
+    net = build_network(seed=0, amplify=False, S=SPP, non_rigid=True, device=dev)
     net.cfg.perturb = 1.0
     net.cfg.train_precision = 'bf16'
     net.train()
@@ -201,9 +194,9 @@ def main():
 
     from occnerf_amd import ops, synth
     from occnerf_amd.parallel import ShardedRenderer
-    from tests.gpu_util import build_network
+    from occnerf_amd.seeded import build_network, host_frame
 
-    net, ctx = build_network(seed=0, amplify=False, S=SPP, non_rigid=True, device=dev)
+    net = build_network(seed=0, amplify=False, S=SPP, non_rigid=True, device=dev)
     frame = synth.make_frame(img_size=IMG, pose72=synth.seeded_pose(1), orbit_frame=28)
     frame_h = host_frame(frame)
     R = frame['rays'].shape[1]
@@ -324,7 +317,8 @@ def main():
         }
         line.update(side)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(ctx, frame, args.cpu_rays)
+            from oracle.chain import model_context                  # the checker, timed as the stated CPU baseline
+            line['cpu_baseline'] = cpu_baseline(model_context(0, False), frame, args.cpu_rays)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define OCCNERF_ABI_VERSION 1
+/* Bumped whenever an existing export's signature or a table layout changes (2: composite/msknn_clustered/
+ * sample_features grew arguments in round 2, the Adam table row carries per-tensor bias corrections). */
+#define OCCNERF_ABI_VERSION 2
 
 int occnerf_abi_version(void);
 const char *occnerf_last_error(void);
@@ -442,15 +444,15 @@ int occnerf_convt3d_im2col(const float *gy, int32_t Cout, int32_t D, int32_t H, 
 
 /* Optimiser step on the device: the reference's clip_grad_norm_(parameters, max_norm) + torch.optim.Adam.step()
  * (trainer.py:248-249, optimizer.py:12-43) as one multi-tensor pass.  table: n_tensors rows of
- * occnerf_adam_table_row_bytes() = 48 bytes in DEVICE memory, each {float *param; const float *grad; float *exp_avg;
- * float *exp_avg_sq; int64 numel; float lr; float pad}; chunks[n_chunks,2] int32 = (tensor index, chunk index), a
- * chunk being chunk_elems consecutive elements of its tensor; bias_corr1 = 1 - beta1^t, bias_corr2_sqrt =
- * sqrt(1 - beta2^t); max_grad_norm <= 0: no clipping.  scratch: n_chunks + 1 floats; scratch[0] receives the squared
+ * occnerf_adam_table_row_bytes() = 56 bytes in DEVICE memory, each {float *param; const float *grad; float *exp_avg;
+ * float *exp_avg_sq; int64 numel; float lr; float bias_corr1 = 1 - beta1^t; float bias_corr2_sqrt = sqrt(1 - beta2^t);
+ * float pad} with t the step count of THAT tensor (torch.optim.Adam keeps one per parameter); chunks[n_chunks,2] int32 =
+ * (tensor index, chunk index), a chunk being chunk_elems consecutive elements of its tensor; max_grad_norm <= 0: no clipping.  scratch: n_chunks + 1 floats; scratch[0] receives the squared
  * global gradient norm.  Nothing visits the host. */
 int32_t occnerf_adam_table_row_bytes(void);
 int occnerf_adam_step(const void *table, int32_t n_tensors, const int32_t *chunks, int32_t n_chunks,
-                      int32_t chunk_elems, double beta1, double beta2, double eps, double bias_corr1,
-                      double bias_corr2_sqrt, double max_grad_norm, float *scratch, void *stream);
+                      int32_t chunk_elems, double beta1, double beta2, double eps, double max_grad_norm, float *scratch,
+                      void *stream);
 
 #ifdef __cplusplus
 }

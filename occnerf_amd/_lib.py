@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liboccnerf_hip.so')
 
+ABI_VERSION = 2          # include/occnerf_hip.h OCCNERF_ABI_VERSION this binding mirrors
+
 _vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
 # name -> (restype, argtypes); mirrors include/occnerf_hip.h one to one
@@ -87,7 +89,7 @@ SIGNATURES = {
     'occnerf_convt3d_col2im': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'occnerf_convt3d_im2col': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'occnerf_adam_table_row_bytes': (_i32, []),
-    'occnerf_adam_step': (C.c_int, [_vp, _i32, _vp, _i32, _i32] + [C.c_double] * 6 + [_vp, _vp]),
+    'occnerf_adam_step': (C.c_int, [_vp, _i32, _vp, _i32, _i32] + [C.c_double] * 4 + [_vp, _vp]),
 }
 
 _lib = None
@@ -110,8 +112,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)            # AttributeError if the ABI drifted
             fn.restype, fn.argtypes = res, args
-        if handle.occnerf_abi_version() != 1:
-            raise ImportError('liboccnerf_hip.so: ABI version mismatch')
+        if handle.occnerf_abi_version() != ABI_VERSION:
+            raise ImportError(f'liboccnerf_hip.so: ABI version {handle.occnerf_abi_version()}, this binding was written '
+                              f'for {ABI_VERSION} (include/occnerf_hip.h OCCNERF_ABI_VERSION): rebuild the library')
         _lib = handle
     return _lib
 

@@ -13,16 +13,18 @@
 namespace occ {
 namespace opt {
 
-struct AdamTensor {          // one row of the device-side table (48 bytes)
+struct AdamTensor {          // one row of the device-side table (56 bytes)
     float *p;
     const float *g;
     float *m;
     float *v;
     int64_t n;
     float lr;
+    float bc1;            // 1 - beta1^t with THIS tensor's step count t (torch.optim.Adam keeps a step per parameter:
+    float bc2_sqrt;       // sqrt(1 - beta2^t)      a parameter may start receiving gradients later than the others)
     float pad_;
 };
-static_assert(sizeof(AdamTensor) == 48, "table row layout is part of the ABI");
+static_assert(sizeof(AdamTensor) == 56, "table row layout is part of the ABI");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -69,17 +71,15 @@ __global__ __launch_bounds__(1024) void sqnorm_final_kernel(const float *__restr
 
 struct AdamHyper {
     float beta2, one_m_beta1, one_m_beta2, eps;      // 1 - beta formed in double on the host, as torch does
-    float bc1;            // 1 - beta1^t
-    float bc2_sqrt;       // sqrt(1 - beta2^t)
     float max_norm;       // <= 0: no clipping
 };
 
-__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float lr, float coef, const AdamHyper &h) {
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, const AdamTensor &t, float coef, const AdamHyper &h) {
     g *= coef;
     m = m + (g - m) * h.one_m_beta1;                                // torch: exp_avg.lerp_(grad, 1 - beta1)
     v = v * h.beta2 + h.one_m_beta2 * g * g;                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
-    p -= (lr / h.bc1) * (m / denom);
+    const float denom = sqrtf(v) / t.bc2_sqrt + h.eps;
+    p -= (t.lr / t.bc1) * (m / denom);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor *__restrict__ tab, const int32_t *__restrict__ chunks,
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor *__restrict_
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 float pe = p[e], me = m[e], ve = v[e];
-                adam1(pe, g[e], me, ve, t.lr, coef, h);
+                adam1(pe, g[e], me, ve, t, coef, h);
                 p[e] = pe;
                 m[e] = me;
                 v[e] = ve;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor *__restrict_
         }
         tail = begin + (n4 << 2);
     }
-    for (int64_t i = tail + threadIdx.x; i < end; i += blockDim.x) adam1(t.p[i], t.g[i], t.m[i], t.v[i], t.lr, coef, h);
+    for (int64_t i = tail + threadIdx.x; i < end; i += blockDim.x) adam1(t.p[i], t.g[i], t.m[i], t.v[i], t, coef, h);
 }
 
 }  // namespace opt
@@ -126,21 +126,19 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor *__restrict_
 OCC_API int32_t occnerf_adam_table_row_bytes(void) { return (int32_t)sizeof(occ::opt::AdamTensor); }
 
 OCC_API int occnerf_adam_step(const void *table, int32_t n_tensors, const int32_t *chunks, int32_t n_chunks,
-                              int32_t chunk_elems, double beta1, double beta2, double eps, double bias_corr1,
-                              double bias_corr2_sqrt, double max_grad_norm, float *scratch, void *stream) {
+                              int32_t chunk_elems, double beta1, double beta2, double eps, double max_grad_norm,
+                              float *scratch, void *stream) {
     using namespace occ;
     OCC_REQUIRE(table && chunks && scratch, "adam_step: null argument");
     OCC_REQUIRE(n_tensors > 0 && n_chunks > 0 && chunk_elems >= 1024 && chunk_elems % 4 == 0,
                 "adam_step: n_tensors=%d n_chunks=%d chunk_elems=%d", n_tensors, n_chunks, chunk_elems);
-    OCC_REQUIRE(bias_corr1 > 0.0 && bias_corr2_sqrt > 0.0, "adam_step: bias corrections must be positive (step >= 1)");
     const opt::AdamTensor *tab = reinterpret_cast<const opt::AdamTensor *>(table);
     hipStream_t st = as_stream(stream);
     if (max_grad_norm > 0.0) {
         hipLaunchKernelGGL(opt::grad_sqnorm_kernel, dim3(n_chunks), dim3(256), 0, st, tab, chunks, chunk_elems, scratch + 1);
         hipLaunchKernelGGL(opt::sqnorm_final_kernel, dim3(1), dim3(1024), 0, st, scratch + 1, n_chunks, scratch);
     }
-    opt::AdamHyper h{(float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)bias_corr1,
-                     (float)bias_corr2_sqrt, (float)max_grad_norm};
+    opt::AdamHyper h{(float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)max_grad_norm};
     hipLaunchKernelGGL(opt::adam_kernel, dim3(n_chunks), dim3(256), 0, st, tab, chunks, chunk_elems, scratch, h);
     return check_launch("adam_step");
 }

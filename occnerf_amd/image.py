@@ -71,7 +71,8 @@ class ImageWriter:
         os.makedirs(self.image_dir, exist_ok=True)
         self.frame_idx = -1
         self._jobs = queue.Queue()
-        self._free = queue.Queue()
+        self._queue_cls = queue.Queue
+        self._free = {}                                         # image shape -> queue of free pinned stages of that shape
         self._stages, self._n_stages = {}, stages
         self._error = None
         self._thread = threading.Thread(target=self._work, daemon=True)
@@ -91,7 +92,7 @@ class ImageWriter:
             except Exception as e:                              # surfaced by finalize()
                 self._error = e
             if stage is not None:
-                self._free.put(stage)
+                self._free[tuple(stage.shape)].put(stage)
 
     def _name(self, img_name):
         self.frame_idx += 1
@@ -107,13 +108,12 @@ class ImageWriter:
         name = self._name(img_name)
         key = tuple(image_u8.shape)
         pool = self._stages.setdefault(key, [])
+        free = self._free.setdefault(key, self._queue_cls())    # one queue per shape: frames of mixed sizes never starve
         if len(pool) < self._n_stages:
             stage = torch.empty(key, dtype=torch.uint8).pin_memory()
             pool.append(stage)
         else:
-            stage = self._free.get()                            # blocks only when the encoder is `stages` frames behind
-            while tuple(stage.shape) != key:
-                stage = self._free.get()
+            stage = free.get()                                  # blocks only when the encoder is `stages` frames behind
         stage.copy_(image_u8, non_blocking=True)
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(image_u8.device))

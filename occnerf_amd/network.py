@@ -27,6 +27,7 @@ import torch.nn as nn
 from . import geometry, ops
 from .canonical_mlp import CanonicalMLP
 from .config import get_cfg
+from .rayorder import ray_patch_order
 from .modules import (BodyPoseRefiner, MotionBasisComputer, MotionWeightVolumeDecoder,
                       NonRigidMotionMLP, hann_window_weights)
 
@@ -342,35 +343,9 @@ class Network(nn.Module):
 
     @staticmethod
     def _ray_patch_order(rays_d):
-        """Permutation that walks the rays along a 2-D Morton curve of their directions (projected
-        on the plane normal to the mean direction): 64 consecutive rays then form a compact
-        ~8x8 pixel patch, which is what the kNN tiles and the hash-grid gathers want.  Rays are
-        independent, so the order is free; outputs are returned in the caller's order.
-        All on the device, no host sync."""
-        with torch.autocast('cuda', enabled=False):            # (a caller's autocast must not quantise the sort keys)
-            return Network._ray_patch_order_fp32(rays_d.float())
-
-    @staticmethod
-    def _ray_patch_order_fp32(rays_d):
-        d = rays_d / rays_d.norm(dim=1, keepdim=True).clamp_min(1e-20)
-        m = d.mean(dim=0)
-        axis = torch.zeros(3, device=d.device, dtype=d.dtype).scatter_(0, m.abs().argmin().view(1), 1.0)
-        e1 = torch.linalg.cross(m, axis)
-        e1 = e1 / e1.norm().clamp_min(1e-20)
-        e2 = torch.linalg.cross(m, e1)
-        e2 = e2 / e2.norm().clamp_min(1e-20)
-        uv = torch.stack([d @ e1, d @ e2], dim=1)
-        lo = uv.min(dim=0, keepdim=True).values
-        span = (uv.max(dim=0, keepdim=True).values - lo).max().clamp_min(1e-20)
-        q = ((uv - lo) / span * 65535.0).long().clamp_(0, 65535)
-
-        def spread(x):                       # 16 bits -> every second bit
-            x = (x | (x << 8)) & 0x00FF00FF
-            x = (x | (x << 4)) & 0x0F0F0F0F
-            x = (x | (x << 2)) & 0x33333333
-            x = (x | (x << 1)) & 0x55555555
-            return x
-        return torch.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1))
+        """Morton walk of the rays (occnerf_amd/rayorder.py): 64 consecutive rays form a compact ~8x8 pixel patch.
+        Outputs are returned in the caller's order."""
+        return ray_patch_order(rays_d)
 
     @staticmethod
     def _host3(v):

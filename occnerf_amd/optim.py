@@ -38,12 +38,13 @@ class FusedAdam(torch.optim.Optimizer):
             for c in range((p.numel() + CHUNK - 1) // CHUNK):
                 chunks.append((ti, c))
         row = int(_lib.lib().occnerf_adam_table_row_bytes())
-        assert row == 48
-        hosts = [torch.zeros(len(items), 6, dtype=torch.int64).pin_memory() for _ in range(2)]   # p, g, m, v, n, (lr | pad)
+        assert row == 56
+        # p, g, m, v, n, (lr | bias_corr1), (bias_corr2_sqrt | pad)
+        hosts = [torch.zeros(len(items), 7, dtype=torch.int64).pin_memory() for _ in range(2)]
         return {
             'key': tuple(id(p) for _, p in items), 'device': dev, 'hosts': hosts, 'np': [h.numpy() for h in hosts],
             'events': [None, None], 'turn': 0,
-            'table': torch.zeros(len(items), 6, dtype=torch.int64, device=dev),
+            'table': torch.zeros(len(items), 7, dtype=torch.int64, device=dev),
             'chunks': torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous(),
             'scratch': torch.zeros(len(chunks) + 1, dtype=torch.float32, device=dev),
         }
@@ -66,8 +67,14 @@ class FusedAdam(torch.optim.Optimizer):
         if plan['events'][turn] is not None:                 # be queued when step t fills its table
             plan['events'][turn].synchronize()
         host = plan['np'][turn]
-        step = None
-        betas = eps = None
+        # validate BEFORE touching any state: a refused step must leave the optimiser as it was
+        betas, eps = tuple(self.param_groups[items[0][0]]['betas']), float(self.param_groups[items[0][0]]['eps'])
+        for gi, _ in items:
+            group = self.param_groups[gi]
+            if tuple(group['betas']) != betas or float(group['eps']) != eps:
+                raise RuntimeError('FusedAdam: every parameter group must share betas and eps')
+        b1, b2 = betas
+        keep = []                                            # contiguous copies of strided gradients: alive until the launch
         for ti, (gi, p) in enumerate(items):
             group = self.param_groups[gi]
             st = self.state[p]
@@ -76,27 +83,29 @@ class FusedAdam(torch.optim.Optimizer):
                 st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st['step'] += 1
-            s = int(st['step'])
-            if step is None:
-                step, betas, eps = s, tuple(group['betas']), float(group['eps'])
-            elif s != step or tuple(group['betas']) != betas or float(group['eps']) != eps:
-                raise RuntimeError('FusedAdam: every parameter must share step count, betas and eps')
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            # a step count per parameter, as torch.optim.Adam: a parameter whose first gradient arrives late (the pose
+            # refiner before pose_decoder.kick_in_iter, staged unfreezing, a resumed torch state) has its own bias corrections
+            t = int(st['step'])
+            g = p.grad
+            if not g.is_contiguous():
+                g = g.contiguous()
+                keep.append(g)
             host[ti, 0], host[ti, 1] = p.data_ptr(), g.data_ptr()
             host[ti, 2], host[ti, 3] = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
             host[ti, 4] = p.numel()
-            host[ti, 5] = int(np.float32(group['lr']).view(np.uint32))          # low word = lr bits, high word = pad
+            host[ti, 5] = int(np.float32(group['lr']).view(np.uint32)) | \
+                (int(np.float32(1.0 - b1 ** t).view(np.uint32)) << 32)          # low word lr, high word 1 - beta1^t
+            host[ti, 6] = int(np.float32(math.sqrt(1.0 - b2 ** t)).view(np.uint32))
         plan['table'].copy_(plan['hosts'][turn], non_blocking=True)
         ev = plan['events'][turn] = plan['events'][turn] or torch.cuda.Event()
         ev.record(torch.cuda.current_stream(plan['device']))
-        b1, b2 = betas
         with ops._guard_dev(plan['device']):
             rc = _lib.lib().occnerf_adam_step(
                 plan['table'].data_ptr(), len(items), plan['chunks'].data_ptr(), plan['chunks'].shape[0], CHUNK,
-                float(b1), float(b2), float(eps), float(1.0 - b1 ** step), float(math.sqrt(1.0 - b2 ** step)),
-                float(max_grad_norm) if max_grad_norm else 0.0, plan['scratch'].data_ptr(),
+                float(b1), float(b2), float(eps), float(max_grad_norm) if max_grad_norm else 0.0, plan['scratch'].data_ptr(),
                 torch.cuda.current_stream(plan['device']).cuda_stream)
         _lib.check(rc, 'adam_step')
+        del keep                                             # the launch is queued behind the copies on the same stream
         # the kernel wrote the parameters behind torch's back: move their version counters, which is what autograd's
         # saved-tensor checks and the renderer's per-version caches (packed MLP weights, decoded volume, point table) key on
         for _, p in items:

@@ -1,20 +1,33 @@
 """Multi-GPU: rays shard, one process per GPU, one gather per frame.
 
 Rays are independent (the only cross-sample dependency is the scan inside one ray), so a frame's
-`ray_mask`-compacted ray list is dealt to the ranks in chunks of 4 096 consecutive rays; every rank holds the
-full (61 MiB) model, renders its rays with no data-path collective, and the `[R/N, 5]` (rgb, alpha, depth)
-blocks are gathered on rank 0 over RCCL/xGMI (<= 5.2 MB per 512^2 frame: latency-bound, one collective).
-This replaces the reference's nn.DataParallel over *samples* with its per-call weight broadcast
-(network.py:68-72,142-146); it does not mirror it.
+`ray_mask`-compacted ray list is dealt to the ranks in small blocks; every rank holds the full (61 MiB) model,
+renders its rays with no data-path collective, and the `[R/N, 5]` (rgb, alpha, depth) blocks are gathered on rank 0
+over RCCL/xGMI (<= 5.2 MB per 512^2 frame: latency-bound, one collective).  This replaces the reference's
+nn.DataParallel over *samples* with its per-call weight broadcast (network.py:68-72,142-146); it does not mirror it.
 
-`ShardedRenderer` keeps everything that does not change from frame to frame -- the shard index lists, the
-un-permutation that puts the gathered blocks back into the caller's ray order, the padded send / receive
-buffers (two slots) -- and issues the gather asynchronously, so that frame t's gather runs under frame t+1's
-kernels (`render_frames`).  A rank whose shard is empty (fewer rays than ranks x chunk) skips the render and
-still takes part in the gather.
+**Which rays go where.**  The frame's rays are first walked along the renderer's 2-D Morton curve
+(`rayorder.ray_patch_order`, the order `Network` renders in anyway), and that walk is dealt to the ranks in blocks of
+256 consecutive rays (a ~16x16 pixel patch), block b to rank b % N.  Three things follow: (i) the shares differ by at
+most one block -- max/mean rays per rank <= 1.003 at N = 8 for the 183 784-ray benchmark frame (the 4 096-ray chunks
+of round 2: 1.07); (ii) a rank's share is hundreds of patches spread over the whole image, so the *cost* per rank
+(live samples: a quarter of the samples are dead, unevenly over the image) evens out statistically
+(tools/shard_balance.py prints it); (iii) a block is a multiple of the 64-ray kNN tile and stays a compact pixel
+patch, so a rank's kernels see the same locality as a single GPU's.
+
+`ShardedRenderer` keeps what does not change from frame to frame -- the shard index lists and the un-permutation
+into the caller's ray order (per `ray_order_key`: a sequence shot by one camera names it, as `Network.forward`'s
+Morton cache does), padded send / receive buffers in two slots -- and issues the gather asynchronously, so that frame
+t's gather runs under frame t+1's kernels (`render_frames`).  A rank whose shard is empty (fewer blocks than ranks)
+skips the render and still takes part in the gather.
 """
 import torch
 import torch.distributed as dist
+
+from .rayorder import ray_patch_order
+
+BLOCK = 256          # rays per dealt block: 4 kNN tiles, a ~16x16 pixel patch
+WIDTH_QUANTUM = 4096  # buffers are sized in multiples of this many rays so that frames of a sequence share them
 
 
 def shard_bounds(n_rays, world_size):
@@ -28,17 +41,30 @@ def shard_bounds(n_rays, world_size):
     return bounds
 
 
-def shard_indices(n_rays, rank, world_size, chunk=4096):
-    """Ray indices of `rank` when rays are dealt in chunks of `chunk` consecutive rays (chunk c -> rank
-    c % world_size).  Contiguous blocks of a pixel-ordered ray list are horizontal image bands with very
-    different amounts of body in them; dealing chunks balances the work, and a chunk is still a compact
-    set of pixels for the kNN tiles.  Every rank gets the same number of rays +- one chunk."""
-    idx = torch.arange(int(n_rays))
-    return idx[(idx // int(chunk)) % int(world_size) == int(rank)]
+def shard_sizes(n_rays, world_size, block=BLOCK):
+    """Rays per rank when `n_rays` positions are dealt in blocks of `block` (block b -> rank b % world_size)."""
+    n_rays, world_size, block = int(n_rays), int(world_size), int(block)
+    full, tail = divmod(n_rays, block)
+    sizes = [(full // world_size + (1 if r < full % world_size else 0)) * block for r in range(world_size)]
+    if tail:
+        sizes[full % world_size] += tail
+    return sizes
+
+
+def shard_positions(n_rays, rank, world_size, block=BLOCK, device=None):
+    """Positions (in the dealt walk) of `rank`'s rays, ascending; pure arithmetic, no data-dependent shapes."""
+    size = shard_sizes(n_rays, world_size, block)[int(rank)]
+    j = torch.arange(size, device=device)
+    return (torch.div(j, block, rounding_mode='floor') * world_size + int(rank)) * block + j % block
+
+
+def shard_indices(n_rays, rank, world_size, chunk=BLOCK):
+    """Ray indices of `rank` when the caller's own order is dealt (no Morton walk): chunk c -> rank c % world_size."""
+    return shard_positions(n_rays, rank, world_size, chunk)
 
 
 def shard_frame(data, rank, world_size):
-    """Slice the per-ray entries of a frame dict (rays[2,R,3], near/far[R,1]) for `rank`."""
+    """Slice the per-ray entries of a frame dict (rays[2,R,3], near/far[R,1]) for `rank` (contiguous blocks)."""
     R = data['rays'].shape[1]
     lo, hi = shard_bounds(R, world_size)[rank]
     out = dict(data)
@@ -65,146 +91,208 @@ def gather_rays(block, n_rays, dst=0, group=None):
 
 
 class _Pending:
-    """One frame in flight: the gather's work handle, its plan (buffers) and the slot used."""
-    __slots__ = ('work', 'slot', 'n_rays', 'plan')
+    """One frame in flight: the gather's work handle, its plan and buffers and the slot used."""
+    __slots__ = ('work', 'slot', 'n_rays', 'plan', 'bufs')
 
-    def __init__(self, work, slot, n_rays, plan):
-        self.work, self.slot, self.n_rays, self.plan = work, slot, n_rays, plan
+    def __init__(self, work, slot, n_rays, plan, bufs):
+        self.work, self.slot, self.n_rays, self.plan, self.bufs = work, slot, n_rays, plan, bufs
 
 
 class ShardedRenderer:
     """Renders frames with their rays sharded over the ranks of `group` (see the module docstring)."""
 
-    def __init__(self, net, device, group=None, chunk=4096, channels=5, single=False):
-        """single: ignore the process group, this process renders whole frames by itself."""
-        self.net, self.device, self.group, self.chunk, self.channels = net, torch.device(device), group, int(chunk), channels
+    def __init__(self, net, device, group=None, block=BLOCK, channels=5, single=False, morton=True, chunk=None):
+        """single: ignore the process group, this process renders whole frames by itself.  morton=False deals the
+        caller's own ray order.  chunk: older name of `block`."""
+        self.net, self.device, self.group, self.channels = net, torch.device(device), group, channels
+        self.block = int(chunk if chunk is not None else block)
+        self.morton = bool(morton)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() and not single else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         # gloo has no gather on device tensors: with that backend (tests: several processes sharing one GPU) the blocks
         # are exchanged through host buffers; with nccl (= RCCL) they stay on the device
         self.host_exchange = self.world > 1 and self.device.type == 'cuda' and dist.get_backend(group) == 'gloo'
-        self._plans = {}          # rays per frame -> shard plan with its buffers (frames in flight keep theirs)
+        self._plans = {}          # (rays per frame, ray_order_key) -> shard plan (index lists)
+        self._bufs = {}           # padded width -> send / receive / staging buffers, two slots
         self._turn = 0
+        self.last_shard_rays = None      # rays this rank rendered in the last submitted frame
 
     def formed_world_size(self):
         """World size the process group actually formed (what bench.py prints)."""
         return self.world
 
-    def _get_plan(self, R):
-        hit = self._plans.get(R)
-        if hit is not None:
-            return hit
-        shards = [shard_indices(R, r, self.world, self.chunk) for r in range(self.world)]
-        sizes = [int(s.numel()) for s in shards]
-        width = max(max(sizes), 1)
-        plan = {'R': R, 'mine_cpu': shards[self.rank], 'mine_dev': shards[self.rank].to(self.device), 'sizes': sizes,
-                'width': width,
-                'send': [torch.zeros(width, self.channels, device=self.device) for _ in range(2)]}
-        if self.host_exchange:
-            plan['send_host'] = [torch.zeros(width, self.channels).pin_memory() for _ in range(2)]
-            if self.rank == 0:
-                plan['recv_host'] = [torch.empty(self.world * width, self.channels).pin_memory() for _ in range(2)]
-        if self.rank == 0 and self.world > 1:
-            # position in the concatenated [world * width] receive buffer of every ray of the frame
-            src = torch.empty(R, dtype=torch.long)
-            for r, s in enumerate(shards):
-                src[s] = r * width + torch.arange(sizes[r])
+    # ------------------------------------------------------------------ plans and buffers
+    def _build_plan(self, rays):
+        R, W, B = int(rays.shape[1]), self.world, self.block
+        sizes = shard_sizes(R, W, B)
+        plan = {'R': R, 'sizes': sizes, 'width': -(-max(max(sizes), 1) // WIDTH_QUANTUM) * WIDTH_QUANTUM}
+        if W == 1:
+            return plan
+        where = rays.device
+        order = ray_patch_order(rays[1]) if self.morton else None             # [R] walk position -> ray index
+        pos = shard_positions(R, self.rank, W, B, device=where)
+        mine = order[pos] if order is not None else pos
+        plan['mine'] = {where.type: mine}
+        if self.rank == 0:
+            # row of the concatenated [world * width] receive buffer that holds walk position p, then per ray index
+            p = torch.arange(R, device=where)
+            blk = torch.div(p, B, rounding_mode='floor')
+            dest = (blk % W) * plan['width'] + torch.div(blk, W, rounding_mode='floor') * B + p % B
+            if order is not None:
+                src = torch.empty_like(dest)
+                src[order] = dest
+            else:
+                src = dest
             plan['unpermute'] = src.to(self.device)
-            plan['recv'] = [torch.empty(self.world * width, self.channels, device=self.device) for _ in range(2)]
-        if len(self._plans) >= 4:                                 # a sequence's frames differ in ray count: keep a few plans
-            self._plans.pop(next(iter(self._plans)))
-        self._plans[R] = plan
         return plan
 
-    def submit(self, data, iter_val=1e7, **net_kwargs):
+    def _get_plan(self, rays, key):
+        R = int(rays.shape[1])
+        if key is None and self.world > 1 and self.morton:
+            return self._build_plan(rays)                         # unnamed camera: the walk is recomputed for this frame
+        k = (R, key)
+        hit = self._plans.get(k)
+        if hit is None:
+            if len(self._plans) >= 16:                            # a sequence's frames differ in ray count: keep a few plans
+                self._plans.pop(next(iter(self._plans)))
+            hit = self._plans[k] = self._build_plan(rays)
+        return hit
+
+    def _mine(self, plan, dev_type):
+        m = plan['mine']
+        if dev_type not in m:
+            m[dev_type] = next(iter(m.values())).to(self.device if dev_type == 'cuda' else 'cpu')
+        return m[dev_type]
+
+    def _get_bufs(self, width):
+        b = self._bufs.get(width)
+        if b is None:
+            if len(self._bufs) >= 4:
+                self._bufs.pop(next(iter(self._bufs)))            # (frames in flight keep their own reference)
+            gpu = self.device.type == 'cuda'
+            b = {'send': [torch.zeros(width, self.channels, device=self.device) for _ in range(2)], 'stage': [None, None]}
+            if self.host_exchange:
+                b['send_host'] = [torch.zeros(width, self.channels).pin_memory() for _ in range(2)]
+                if self.rank == 0:
+                    b['recv_host'] = [torch.empty(self.world * width, self.channels).pin_memory() for _ in range(2)]
+            if self.rank == 0 and self.world > 1:
+                b['recv'] = [torch.empty(self.world * width, self.channels, device=self.device) for _ in range(2)]
+            b['gpu'] = gpu
+            self._bufs[width] = b
+        return b
+
+    # ------------------------------------------------------------------ one frame
+    def submit(self, data, iter_val=1e7, ray_order_key=None, **net_kwargs):
         """Render this rank's share of the frame `data` and start the gather of (rgb, alpha, depth).  Per-ray entries
         (rays[2,R,3], near/far[R,1]) may live on the host (only the shard is then copied to the device) or on the
-        device; every rank passes the same frame."""
-        R = int(data['rays'].shape[1])
-        plan = self._get_plan(R)
+        device; every rank passes the same frame.  ray_order_key: hashable name of the camera -- frames with the same
+        key and ray count reuse the shard plan (and, inside `Network`, the Morton order of the shard)."""
+        rays = data['rays']
+        R = int(rays.shape[1])
+        plan = self._get_plan(rays, ray_order_key)
+        bufs = self._get_bufs(plan['width'])
         slot = self._turn = self._turn ^ 1
-        mine = plan['mine_dev'] if data['rays'].is_cuda else plan['mine_cpu']
         n_mine = plan['sizes'][self.rank]
-        send = plan['send'][slot]
+        self.last_shard_rays = n_mine
+        send = bufs['send'][slot]
         if n_mine:
             local = dict(data)
-            if n_mine == R:                                      # the whole frame is this rank's (one rank)
-                sub = (data['rays'], data['near'], data['far'])
-            elif data['rays'].is_cuda:
-                sub = (data['rays'][:, mine], data['near'][mine], data['far'][mine])
+            if self.world == 1:                                  # the whole frame is this rank's
+                sub = (rays, data['near'], data['far'])
+            elif rays.is_cuda:
+                mine = self._mine(plan, 'cuda')
+                sub = (rays[:, mine], data['near'].reshape(-1, 1)[mine], data['far'].reshape(-1, 1)[mine])
             else:                                                # host frame: gather the shard into PINNED staging buffers, so
-                st = plan.setdefault('stage', [None, None])      # that the copies below really are asynchronous
-                if st[slot] is None:
-                    gpu = self.device.type == 'cuda'
-                    bufs = [torch.empty(2, n_mine, 3), torch.empty(n_mine, 1), torch.empty(n_mine, 1)]
-                    st[slot] = tuple(b.pin_memory() if gpu else b for b in bufs) + (torch.cuda.Event() if gpu else None,)
-                rs, ns, fs, ev = st[slot]
+                mine = self._mine(plan, 'cpu')                   # that the copies below really are asynchronous
+                if bufs['stage'][slot] is None:
+                    w = plan['width']
+                    st = [torch.empty(2, w, 3), torch.empty(w, 1), torch.empty(w, 1)]
+                    bufs['stage'][slot] = tuple(b.pin_memory() if bufs['gpu'] else b for b in st) + \
+                        (torch.cuda.Event() if bufs['gpu'] else None,)
+                rs, ns, fs, ev = bufs['stage'][slot]
                 if ev is not None:
                     ev.synchronize()                             # the copy issued from this slot two frames ago has left it
-                torch.index_select(data['rays'], 1, mine, out=rs)
+                rs, ns, fs = rs[:, :n_mine], ns[:n_mine], fs[:n_mine]
+                torch.index_select(rays, 1, mine, out=rs)
                 torch.index_select(data['near'].reshape(-1, 1), 0, mine, out=ns)
                 torch.index_select(data['far'].reshape(-1, 1), 0, mine, out=fs)
                 sub = (rs, ns, fs)
             local['rays'] = sub[0].to(self.device, non_blocking=True)
             local['near'] = sub[1].to(self.device, non_blocking=True)
             local['far'] = sub[2].to(self.device, non_blocking=True)
-            if not data['rays'].is_cuda and n_mine != R and plan['stage'][slot][3] is not None:
-                plan['stage'][slot][3].record(torch.cuda.current_stream(self.device))
+            if self.world > 1 and not rays.is_cuda and bufs['stage'][slot][3] is not None:
+                bufs['stage'][slot][3].record(torch.cuda.current_stream(self.device))
             for k, v in data.items():
                 if k not in ('rays', 'near', 'far') and torch.is_tensor(v) and not v.is_cuda and v.numel() > 3:
                     local[k] = v.to(self.device, non_blocking=True)
+            if ray_order_key is not None:
+                net_kwargs = dict(net_kwargs, ray_order_key=(ray_order_key, 'shard', self.rank, self.world))
             out = self.net(**local, iter_val=iter_val, **net_kwargs)
             send[:n_mine, :3] = out['rgb']
             send[:n_mine, 3] = out['alpha']
             send[:n_mine, 4] = out['depth']
         if self.world == 1:
-            return _Pending(None, slot, R, plan)
+            return _Pending(None, slot, R, plan, bufs)
         if self.host_exchange:
-            send = plan['send_host'][slot].copy_(send)               # (synchronous: the gloo path is a test vehicle)
-            rbuf = plan['recv_host'][slot] if self.rank == 0 else None
+            send = bufs['send_host'][slot].copy_(send)               # (synchronous: the gloo path is a test vehicle)
+            rbuf = bufs['recv_host'][slot] if self.rank == 0 else None
         else:
-            rbuf = plan['recv'][slot] if self.rank == 0 else None
+            rbuf = bufs['recv'][slot] if self.rank == 0 else None
         recv = list(rbuf.view(self.world, plan['width'], self.channels).unbind(0)) if self.rank == 0 else None
         work = dist.gather(send, recv, dst=0, group=self.group, async_op=True)
-        return _Pending(work, slot, R, plan)
+        return _Pending(work, slot, R, plan, bufs)
 
     def finish(self, pending):
-        """Wait for a frame's gather; -> {'rgb','alpha','depth'} in the caller's ray order on rank 0, None elsewhere."""
-        plan = pending.plan
+        """Wait for a frame's gather; -> {'rgb','alpha','depth'} in the caller's ray order on rank 0, None elsewhere.
+        The tensors are the frame's own (not views of the slot buffers, which the frame after next reuses)."""
+        plan, bufs = pending.plan, pending.bufs
         if self.world == 1:
-            full = plan['send'][pending.slot][:pending.n_rays]
+            full = bufs['send'][pending.slot][:pending.n_rays].clone()
         else:
             pending.work.wait()
             if self.rank != 0:
                 return None
             if self.host_exchange:
-                plan['recv'][pending.slot].copy_(plan['recv_host'][pending.slot], non_blocking=True)
-            full = plan['recv'][pending.slot].index_select(0, plan['unpermute'])
+                bufs['recv'][pending.slot].copy_(bufs['recv_host'][pending.slot], non_blocking=True)
+            full = bufs['recv'][pending.slot].index_select(0, plan['unpermute'])
         return {'rgb': full[:, :3], 'alpha': full[:, 3], 'depth': full[:, 4], 'packed': full}     # packed: contiguous [R,5]
 
     def render_frames(self, frames, iter_val=1e7, **net_kwargs):
-        """Generator over `frames`: frame t's gather overlaps frame t+1's kernels (one frame of lag)."""
+        """Generator over `frames`: frame t's gather overlaps frame t+1's kernels (one frame of lag).  A frame may be a
+        dict or a (dict, ray_order_key) pair."""
         prev = None
-        for data in frames:
-            cur = self.submit(data, iter_val=iter_val, **net_kwargs)
+        for item in frames:
+            data, key = item if isinstance(item, tuple) else (item, None)
+            cur = self.submit(data, iter_val=iter_val, ray_order_key=key, **net_kwargs)
             if prev is not None:
                 yield self.finish(prev)
             prev = cur
         if prev is not None:
             yield self.finish(prev)
 
+    def shard_stats(self):
+        """(rays, live samples) this rank rendered in the last submitted frame; live samples is None when the network
+        does not report them.  One device read: call it outside timed regions."""
+        live = getattr(self.net, 'last_live_count', None) if self.last_shard_rays else 0
+        return int(self.last_shard_rays or 0), (None if live is None else int(live))
+
 
 _renderers = {}
 
 
-def render_frame_sharded(net, data, iter_val=1e7, group=None, chunk=4096):
+def get_renderer(net, device, group=None, block=BLOCK):
+    key = (id(net), str(device), id(group), int(block))
+    r = _renderers.get(key)
+    if r is None:
+        r = _renderers[key] = ShardedRenderer(net, device, group=group, block=block)
+    return r
+
+
+def render_frame_sharded(net, data, iter_val=1e7, group=None, chunk=BLOCK, ray_order_key=None):
     """One frame, synchronously: this rank's share rendered, (rgb, alpha, depth) gathered on rank 0 -- the path's
     only collective.  Returns the full-frame dict in the caller's ray order on rank 0 and None on the other ranks."""
     dev = data['rays'].device
     if dev.type != 'cuda' and hasattr(net, 'point_base'):      # host frame: the shard is copied to the model's device
         dev = net.point_base.device
-    key = (id(net), str(dev), id(group), int(chunk))
-    r = _renderers.get(key)
-    if r is None:
-        r = _renderers[key] = ShardedRenderer(net, dev, group=group, chunk=chunk)
-    return r.finish(r.submit(data, iter_val=iter_val))
+    r = get_renderer(net, dev, group, chunk)
+    return r.finish(r.submit(data, iter_val=iter_val, ray_order_key=ray_order_key))

@@ -167,10 +167,18 @@ def render_rays_autograd_torch(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bg
             tp = term[depth_mask].detach()
             term_pts = torch.gather(cnl_pts[depth_mask].detach(), 1, tp[:, :, None].expand(-1, 1, 3)).squeeze(1)
             kidx = ops.knn_small(term_pts.float().contiguous(), net.point_cloud.detach().float().contiguous(), 10)
-            net.point_counter.data[kidx.view(-1).long()] += 1.                   # duplicates count once
+            _bump_counter(net, kidx)
     else:
         comp_loss = torch.zeros(1, 1, device=rays8.device)
     return rgb, acc, depth, comp_loss
+
+
+def _bump_counter(net, kidx):
+    """network.py:508-510 `point_counter[idx] += 1` (a non-accumulating index_put: duplicates count once).  A write through
+    `.data` does not move the parameter's version counter, and the renderer's cached (geometry, counts) pack is keyed
+    on it (Network._point_pack): move it explicitly, or eval renders after training-mode forwards see stale counts."""
+    net.point_counter.data[kidx.view(-1).long()] += 1.
+    torch.autograd.graph.increment_version(net.point_counter)
 
 
 def _training_branch(net, raw, depth, term, cnl_pts):
@@ -183,7 +191,7 @@ def _training_branch(net, raw, depth, term, cnl_pts):
         tp = term[depth_mask].detach().long()
         term_pts = torch.gather(cnl_pts[depth_mask].detach(), 1, tp[:, :, None].expand(-1, 1, 3)).squeeze(1)
         kidx = ops.knn_small(term_pts.float().contiguous(), net.point_cloud.detach().float().contiguous(), 10)
-        net.point_counter.data[kidx.view(-1).long()] += 1.                       # duplicates count once
+        _bump_counter(net, kidx)
     return comp_loss
 
 
@@ -192,7 +200,7 @@ def _use_bf16(cfg):
     with cfg.train_precision = 'bf16'; exact fp32 otherwise."""
     want = str(cfg.get('train_precision', 'auto'))
     if want == 'auto':
-        return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
     if want not in ('bf16', 'fp32'):
         raise RuntimeError(f"cfg.train_precision must be 'auto', 'bf16' or 'fp32', got {want!r}")
     return want == 'bf16'

@@ -1,6 +1,6 @@
 """Render entry point with the reference's command line (run.py:246-247, configs/config.py:65-72):
 
-    python run.py --cfg configs/occnerf/synthetic/occnerf.yaml --type {tpose,freeview,movement} [KEY VALUE ...]
+    python run.py --cfg configs/occnerf/synthetic/occnerf.yaml --type {tpose,freeview,movement,allview,evaluate} [KEY VALUE ...]
 
 Frames go to experiments/<category>/<task>/<subject>/<experiment>/<load_net>/<folder>/NNNNNN.png
 exactly like the reference (run.py:79-81, image_util.py:53-75).  `load_net: seeded[:N]` renders the
@@ -22,7 +22,7 @@ cfg.bgcolor = [255., 255., 255.]
 from core.data import create_dataloader  # noqa: E402
 from core.nets import create_network  # noqa: E402
 from occnerf_amd.image import ImageWriter, assemble_uint8_device  # noqa: E402
-from occnerf_amd.parallel import render_frame_sharded  # noqa: E402
+from occnerf_amd.parallel import ShardedRenderer  # noqa: E402
 from occnerf_amd.rays import frame_rays  # noqa: E402
 
 EXCLUDE_KEYS_TO_GPU = ['frame_name', 'img_width', 'img_height', 'ray_mask',
@@ -58,20 +58,10 @@ def _init_ranks():
     return rank, world
 
 
-def _render(data_type, folder_name):
-    cfg.perturb = 0.
-    rank, world = _init_ranks()
-    model = create_network()
-    loader = create_dataloader(data_type)
-    model.generate_neural_points(loader.dataset.avg_betas)
-    model = load_network(model).eval()
-    writer = ImageWriter(output_dir=os.path.join(cfg.logdir, str(cfg.load_net).replace(':', '_')),
-                         exp_name=folder_name) if rank == 0 else None
-    n_rays, t_first, n_first = 0, 0.0, 0
+def _frames(loader, data_type, dev):
+    """The loader's frames as (renderer inputs, camera key, bookkeeping): tensors on the device (asynchronously), the three
+    float[3] constants by value, the ray batch generated on the GPU when cfg.device_rays."""
     host_keys = ('bgcolor', 'cnl_bbox_min_xyz', 'cnl_bbox_max_xyz', 'cnl_bbox_scale_xyz')   # float[3]: taken by value
-    torch.cuda.synchronize()
-    t_wall0 = time.perf_counter()
-    idx = -1
     for idx, batch in enumerate(loader):
         batch = {k: (v[0] if torch.is_tensor(v) or isinstance(v, list) else v) for k, v in batch.items()}
         data = {k: (v if k in host_keys else v.cuda(non_blocking=True)) for k, v in batch.items()
@@ -84,40 +74,88 @@ def _render(data_type, folder_name):
             ray_index = torch.nonzero(fr['ray_mask']).squeeze(1)
         else:                            # host mask: the index list is formed on the host, no device round trip
             ray_index = torch.nonzero(batch['ray_mask']).squeeze(1).cuda(non_blocking=True)
-        # a movement sequence is shot by one camera: the renderer's Morton ray order is computed once
-        order_key = ('movement', int(ray_index.numel())) if data_type == 'movement' else None
-        with torch.no_grad():
-            out = render_frame_sharded(model, data, iter_val=cfg.eval_iter) if world > 1 else \
-                model(**data, iter_val=cfg.eval_iter, ray_order_key=order_key)
+        # a movement sequence is shot by one camera: the Morton walk of the rays (shard plan, render order) is computed
+        # once per ray count
+        key = ('movement', int(ray_index.numel())) if data_type == 'movement' else None
+        yield data, key, {'idx': idx, 'ray_index': ray_index, 'width': int(batch['img_width']),
+                          'height': int(batch['img_height'])}
+
+
+def _setup(data_type, **loader_kw):
+    cfg.perturb = 0.
+    rank, world = _init_ranks()
+    model = create_network()
+    loader = create_dataloader(data_type, **loader_kw)
+    model.generate_neural_points(loader.dataset.avg_betas)
+    model = load_network(model).eval()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    return rank, world, model, loader, ShardedRenderer(model, dev), dev
+
+
+def _finish_ranks(rank, world):
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def _render(data_type, folder_name):
+    """run.py:66-119 (_freeview) and :137-186 (run_movement): every frame of the loader through the network, images to
+    <logdir>/<load_net>/<folder>/NNNNNN.png.  One process per GPU: each renders its share of the frame's rays, rank 0
+    receives the gathered (rgb, alpha, depth) while the ranks already render the NEXT frame (ShardedRenderer: one frame of
+    lag), assembles the image on the device and hands the uint8 pixels to the PNG writer thread."""
+    rank, world, model, loader, renderer, dev = _setup(data_type)
+    writer = ImageWriter(output_dir=os.path.join(cfg.logdir, str(cfg.load_net).replace(':', '_')),
+                         exp_name=folder_name) if rank == 0 else None
+    stats = {'rays': 0, 'first_s': 0.0, 'first_rays': 0, 'frames': 0}
+    torch.cuda.synchronize()
+    t_wall0 = time.perf_counter()
+
+    def deliver(pending, meta):
+        out = renderer.finish(pending)
         if out is None:                               # ranks > 0: their rays went to rank 0
-            continue
-        rgb_img, alpha_img = assemble_uint8_device(int(batch['img_width']), int(batch['img_height']), ray_index,
+            return
+        rgb_img, alpha_img = assemble_uint8_device(meta['width'], meta['height'], meta['ray_index'],
                                                    np.array(cfg.bgcolor) / 255., out['rgb'], out['alpha'],
                                                    want_alpha=bool(cfg.show_alpha))
         img_dev = torch.cat([rgb_img, alpha_img], dim=1) if cfg.show_alpha else rgb_img
         # uint8 over PCIe into a pinned staging buffer; the writer thread waits for the copy and encodes the PNG
         # while the next frame renders (nothing here blocks on the GPU)
-        writer.append_device(img_dev, img_name=f'{idx:06d}' if data_type == 'movement' else None)
-        n_rays += int(ray_index.numel())
-        if idx == 0:                                   # includes weight packing and the per-model kNN layout
+        writer.append_device(img_dev, img_name=f"{meta['idx']:06d}" if data_type == 'movement' else None)
+        stats['rays'] += int(meta['ray_index'].numel())
+        stats['frames'] += 1
+        if meta['idx'] == 0:                           # includes weight packing and the per-model kNN layout
             torch.cuda.synchronize()
-            t_first, n_first = time.perf_counter() - t_wall0, int(ray_index.numel())
-    if world > 1:
-        torch.distributed.barrier()
-        if rank != 0:
-            torch.distributed.destroy_process_group()
-            return
+            stats['first_s'], stats['first_rays'] = time.perf_counter() - t_wall0, int(meta['ray_index'].numel())
+
+    prev = None
+    with torch.no_grad():
+        for data, key, meta in _frames(loader, data_type, dev):
+            cur = renderer.submit(data, iter_val=cfg.eval_iter, ray_order_key=key)
+            if prev is not None:
+                deliver(*prev)
+            prev = (cur, meta)
+        if prev is not None:
+            deliver(*prev)
+    if rank != 0:
+        _finish_ranks(rank, world)
+        return
     torch.cuda.synchronize()
     t_render = time.perf_counter() - t_wall0
     writer.finalize()
+    n_rays = stats['rays']
     print(f'{n_rays} rays in {t_render:.3f} s -> {n_rays / max(t_render, 1e-9):.0f} rays/s (frame generation and image '
           f'assembly included; PNG encoding runs beside it)')
-    if idx > 0:
-        print(f'first frame {t_first * 1e3:.0f} ms; frames 2..{idx + 1}: '
-              f'{(n_rays - n_first) / max(t_render - t_first, 1e-9):.0f} rays/s; wall clock with PNG writing '
-              f'{time.perf_counter() - t_wall0:.2f} s')
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    if stats['frames'] > 1:
+        print(f"first frame {stats['first_s'] * 1e3:.0f} ms; frames 2..{stats['frames']}: "
+              f"{(n_rays - stats['first_rays']) / max(t_render - stats['first_s'], 1e-9):.0f} rays/s; wall clock with PNG "
+              f'writing {time.perf_counter() - t_wall0:.2f} s')
+    _finish_ranks(rank, world)
+
+
+def PSNR(img1, img2, scale=255.):
+    """run.py:21-23."""
+    mse = torch.mean((img1 - img2) ** 2)
+    return 20 * torch.log10(scale / torch.sqrt(mse))
 
 
 def run_tpose():
@@ -133,8 +171,42 @@ def run_movement():
     _render('movement', 'movement' if not cfg.render_folder_name else cfg.render_folder_name)
 
 
+def run_allview():
+    """run.py:188-192: the frame cfg.freeview.frame_idx from every camera of the rig."""
+    _render('allview', f'allview_{cfg.freeview.frame_idx}' if not cfg.render_folder_name else cfg.render_folder_name)
+
+
+def run_evaluate():
+    """run.py:194-244: PSNR of the rendered rays against the frames' target colours over the `progress` frames (frames
+    4 and 15 skipped, the network called with iter_val = 1 exactly as the reference does, run.py:224-230: pose refinement
+    and the non-rigid condition are then below their kick-in iterations).  The
+    synthetic source has no photographs: its targets are a teacher's render of the same rays (the seeded, amplified
+    checkpoint `cfg.evaluate_teacher`, like train.py's supervision).  Metrics beyond PSNR are out of scope."""
+    from occnerf_amd.checkpoint import make_state_dict
+    rank, world, model, loader, renderer, dev = _setup('progress', evaluate=True)
+    teacher = create_network()
+    teacher.generate_neural_points(loader.dataset.avg_betas)
+    seed = int(cfg.get('evaluate_teacher_seed', 1))
+    teacher.load_state_dict(make_state_dict(teacher.point_base.detach().numpy(), float(teacher.bound), seed=seed,
+                                            amplify=True), strict=True)
+    teacher = teacher.to(dev).eval()
+    teach = ShardedRenderer(teacher, dev)
+    psnrs, skips = [], [4, 15]
+    with torch.no_grad():
+        for data, key, meta in _frames(loader, 'progress', dev):
+            if meta['idx'] in skips:
+                continue
+            target = teach.finish(teach.submit(data, iter_val=cfg.eval_iter))
+            out = renderer.finish(renderer.submit(data, iter_val=1))       # run.py:224 `batch['iter_val'] = torch.full((1,), 1)`
+            if out is not None:
+                psnrs.append(PSNR(out['rgb'], target['rgb'], 1.))
+    if rank == 0:
+        print('AVG PSNR %.4f' % torch.mean(torch.stack(psnrs)))
+    _finish_ranks(rank, world)
+
+
 if __name__ == '__main__':
     fn = globals().get(f'run_{args.type}')
     if fn is None:
-        raise SystemExit(f"--type {args.type}: supported here are tpose, freeview, movement")
+        raise SystemExit(f"--type {args.type}: supported are tpose, freeview, movement, allview, evaluate")
     fn()

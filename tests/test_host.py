@@ -64,13 +64,56 @@ def test_shard_bounds():
 
 
 def test_shard_indices_partition():
-    from occnerf_amd.parallel import shard_indices
-    for n, w, c in [(183784, 8, 4096), (1001, 2, 64), (7, 8, 4), (0, 2, 16), (5000, 3, 4096)]:
+    from occnerf_amd.parallel import shard_indices, shard_sizes
+    for n, w, c in [(183784, 8, 256), (1001, 2, 64), (7, 8, 4), (0, 2, 16), (5000, 3, 4096), (734200, 8, 256)]:
         parts = [shard_indices(n, r, w, c) for r in range(w)]
         allidx = torch.cat(parts).sort().values
         assert torch.equal(allidx, torch.arange(n))
         sizes = [p.numel() for p in parts]
+        assert sizes == shard_sizes(n, w, c)
         assert max(sizes) - min(sizes) <= c
+
+
+def test_shard_plan_is_balanced():
+    """4 096-ray chunks capped 8-GPU strong scaling at 0.935 before the first kernel ran.  With the
+    default block the largest share is within 1 % of the mean at every N for the benchmark frame (183 784 rays) and a
+    config-4 frame (734 200 rays), and a block stays a multiple of the 64-ray kNN tile."""
+    from occnerf_amd.parallel import BLOCK, shard_sizes
+    assert BLOCK % 64 == 0 and BLOCK <= 512
+    for R in (183784, 734200, 262144):
+        for N in (2, 4, 8):
+            sizes = shard_sizes(R, N)
+            assert sum(sizes) == R
+            assert max(sizes) / (R / N) <= 1.01, (R, N, sizes)
+
+
+def test_morton_plan_matches_positions():
+    """The shard plan built from the Morton walk: every ray exactly once, rank r's rays are the walk's blocks r, r+N, ...
+    and the un-permutation sends each ray's row of the receive buffer back to the caller's index."""
+    from occnerf_amd.parallel import ShardedRenderer
+    from occnerf_amd.rayorder import ray_patch_order
+    g = torch.Generator().manual_seed(1)
+    R, W, B = 3000, 4, 64
+    rays = torch.randn(2, R, 3, generator=g)
+    rays[1] += torch.tensor([0., 0., 8.])
+    order = ray_patch_order(rays[1])
+    assert torch.equal(order.sort().values, torch.arange(R))
+    seen = []
+    for rank in range(W):
+        r = ShardedRenderer(None, 'cpu', block=B, single=True)
+        r.world, r.rank = W, rank                                    # plan arithmetic only: no process group needed
+        plan = r._build_plan(rays)
+        mine = plan['mine']['cpu']
+        want = torch.cat([order[b * B:(b + 1) * B] for b in range(rank, -(-R // B), W)])
+        assert torch.equal(mine, want) and mine.numel() == plan['sizes'][rank]
+        seen.append(mine)
+        if rank == 0:
+            unperm, width = plan['unpermute'], plan['width']
+    assert torch.equal(torch.cat(seen).sort().values, torch.arange(R))
+    recv = torch.full((W * width,), -1, dtype=torch.long)
+    for rank, mine in enumerate(seen):
+        recv[rank * width:rank * width + mine.numel()] = mine         # each rank sends "its ray ids"
+    assert torch.equal(recv[unperm], torch.arange(R))
 
 
 def _free_port():
@@ -102,14 +145,22 @@ def _gloo_worker(rank, world, port, n_rays, q):
     # pipelined: frame t's gather is waited for after frame t+1 has been submitted (two buffer slots, reused)
     from occnerf_amd.parallel import ShardedRenderer
     frames = []
-    for t in range(5):                                    # frames of a sequence differ in ray count
+    for t in range(6):                                    # frames of a sequence differ in ray count
         keep = n_rays - 7 * t
-        frames.append({'rays': data['rays'][:, :keep] * (1.0 + 0.25 * t), 'near': data['near'][:keep] + t,
-                       'far': data['far'][:keep] * 2.0})
+        f = {'rays': data['rays'][:, :keep] * (1.0 + 0.25 * t), 'near': data['near'][:keep] + t,
+             'far': data['far'][:keep] * 2.0}
+        frames.append((f, ('cam', keep)) if t % 2 else f)  # named camera (cached plan) and unnamed (plan per frame)
+    frames.append(frames[1])                              # a cached plan is used again
     r = ShardedRenderer(FakeNet(), 'cpu', chunk=96)
     assert r.formed_world_size() == world
     outs = list(r.render_frames(frames))
-    assert len(outs) == 5
+    assert len(outs) == 7
+    # results are the frames' own tensors, not views of the two slot buffers
+    if rank == 0:
+        assert len({o['packed'].data_ptr() for o in outs}) == len(outs)
+    frames = [f[0] if isinstance(f, tuple) else f for f in frames]
+    if n_rays == 300 and world == 8:
+        assert r.last_shard_rays == (0 if rank >= 4 else r.last_shard_rays) and (rank < 4) == (r.last_shard_rays > 0)
     for o, d in zip(outs, frames):
         ok = ok and (check(o, d) if rank == 0 else o is None)
     if rank == 0:
@@ -120,12 +171,14 @@ def _gloo_worker(rank, world, port, n_rays, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_rays', [1001, 64])
-def test_ray_sharding_gather_gloo_world2(n_rays):
+@pytest.mark.parametrize('n_rays,world', [(1001, 2), (64, 2), (5000, 8), (300, 8)])
+def test_ray_sharding_gather_gloo(n_rays, world):
+    """world 2 and world 8 (the node size the path is built for); 300 rays in blocks of 96 leave ranks 4..7 without a
+    single ray: they skip the render and still join the gather."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n_rays, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, n_rays, q)) for r in range(world)]
     for p in procs:
         p.start()
     assert q.get(timeout=120) is True

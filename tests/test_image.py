@@ -57,6 +57,18 @@ def test_assemble_image_kernel_byte_identical(tmp_path):
     w.finalize()
     for t, want in enumerate(imgs):
         assert np.array_equal(np.asarray(Image.open(tmp_path / 'seq' / f'{t:06d}.png')), want)
+    # frames of mixed sizes, more of each than staging buffers: every shape has its own free queue (a shared one
+    # dropped the other shape's buffers for good and the writer blocked forever)
+    w = ImageWriter(str(tmp_path), 'mixed', stages=2)
+    imgs = []
+    for t in range(9):
+        shape = (16, 24, 3) if t % 3 else (20, 12, 3)
+        img = torch.full(shape, 7 * t, dtype=torch.uint8, device=dev)
+        imgs.append(img.cpu().numpy())
+        w.append_device(img)
+    w.finalize()
+    for t, want in enumerate(imgs):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / 'mixed' / f'{t:06d}.png')), want)
 
 
 @pytest.mark.gpu

@@ -415,6 +415,44 @@ def test_fused_adam_matches_torch(clip):
         assert float(sd_mine['state'][k]['step']) == float(sd_ref['state'][k]['step'])
 
 
+def test_fused_adam_late_parameter_and_strided_grads():
+    """A parameter whose first gradient arrives at step 3 (the pose refiner before pose_decoder.kick_in_iter, staged
+    unfreezing, a resumed torch state) keeps its own step count and bias corrections, as torch.optim.Adam; two
+    non-contiguous gradients in one step are both read from live contiguous copies."""
+    from occnerf_amd.optim import FusedAdam
+    g = torch.Generator(device='cpu').manual_seed(11)
+    shapes = [(300, 70), (129, 33), (5000,), (64, 64)]
+    ref = [torch.randn(s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    mine = [p.detach().clone().requires_grad_(True) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=1e-2)
+    o_mine = FusedAdam(mine, lr=1e-2)
+    for it in range(6):
+        for k, (a, b) in enumerate(zip(ref, mine)):
+            if k == 2 and it < 3:
+                a.grad = b.grad = None                     # parameter 2 joins at the fourth step
+                continue
+            gr = torch.randn(a.shape, generator=g).to(DEV)
+            if k in (0, 1):                                # strided gradients: transposed views
+                gt = torch.randn(a.shape[::-1], generator=g).to(DEV)
+                a.grad, b.grad = gt.t().clone(), gt.t()
+                assert not b.grad.is_contiguous()
+            else:
+                a.grad, b.grad = gr.clone(), gr.clone()
+        o_ref.step()
+        o_mine.step()
+    for a, b in zip(ref, mine):
+        assert _rel(b.detach(), a.detach()) <= 2e-6
+    sr, sm = o_ref.state_dict()['state'], o_mine.state_dict()['state']
+    assert [float(sm[k]['step']) for k in sorted(sm)] == [float(sr[k]['step']) for k in sorted(sr)] == [6., 6., 3., 6.]
+    # a refused step leaves the state untouched
+    o_mine.param_groups[0]['betas'] = (0.9, 0.999)
+    o_bad = FusedAdam([{'params': [mine[0]]}, {'params': [mine[1]], 'betas': (0.8, 0.999)}], lr=1e-2)
+    mine[0].grad, mine[1].grad = torch.ones_like(mine[0]), torch.ones_like(mine[1])
+    with pytest.raises(RuntimeError, match='share betas'):
+        o_bad.step()
+    assert len(o_bad.state) == 0
+
+
 # ------------------------------------------------------------------------------------------ volume decoder
 def test_volume_decoder_gemm_gather_matches_conv_transpose():
     """a4: the GEMM + HIP gather form of the ConvTranspose3d stack (deconv_vol_decoder.py:25-33, network_util.py:12-50)
@@ -473,3 +511,29 @@ def test_autocast_selects_bf16_trunks():
         assert seen[-1] is False
     finally:
         train_ops.canonical_trunks = real
+
+
+def test_eval_render_sees_counter_moved_by_training_forward():
+    """The visibility counter is written through `.data` in training-mode forwards (network.py:508-510); the renderer's
+    cached (geometry, counts) pack must follow it even when no weight changed (no_grad training forwards, gradient
+    accumulation): eval render, train-mode forward under no_grad, eval render == a fresh network carrying the moved counter."""
+    from occnerf_amd import synth
+    net, ctx = build_network(0, True, S=32, non_rigid=True)
+    frame = synth.make_frame(img_size=32, pose72=synth.seeded_pose(2), orbit_frame=3)
+    data = frame_to_device(frame, DEV)
+    with torch.no_grad():
+        before = net(**data, iter_val=1e7)['rgb'].clone()
+        c0 = net.point_counter.detach().clone()
+        v0 = net.point_counter._version
+        net.train()
+        net(**data, iter_val=1e7)
+        net.eval()
+        c1 = net.point_counter.detach().clone()
+        assert int((c1 != c0).sum()) > 0 and net.point_counter._version > v0
+        after = net(**data, iter_val=1e7)['rgb'].clone()
+    fresh, _ = build_network(0, True, S=32, non_rigid=True)
+    with torch.no_grad():
+        fresh.point_counter.copy_(c1)
+        want = fresh(**data, iter_val=1e7)['rgb']
+    assert torch.equal(after, want)
+    assert not torch.equal(after, before)

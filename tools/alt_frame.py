@@ -3,8 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
 from occnerf_amd import synth
-from tests.gpu_util import build_network, frame_to_device
-net, ctx = build_network(seed=0, amplify=False, S=128, non_rigid=True, mlp_precision='bf16x3')
+from occnerf_amd.seeded import build_network, frame_to_device
+net = build_network(seed=0, amplify=False, S=128, non_rigid=True, mlp_precision='bf16x3')
 frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
 data = frame_to_device(frame, 'cuda:0')
 for k in ('cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor'):

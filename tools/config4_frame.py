@@ -4,8 +4,8 @@ import sys, os, time
 sys.path.insert(0, os.getcwd())
 import torch, numpy as np
 from occnerf_amd import synth
-from tests.gpu_util import build_network, frame_to_device
-net, ctx = build_network(seed=0, amplify=False, S=192, non_rigid=True)
+from occnerf_amd.seeded import build_network, frame_to_device
+net = build_network(seed=0, amplify=False, S=192, non_rigid=True)
 # visibility pattern of SURVEY 8(d) C4: ones on a "visible" half, 1 + Poisson(50) elsewhere
 rng = np.random.RandomState(4)
 pc = net.point_base.detach().cpu().numpy()

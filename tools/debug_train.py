@@ -1,11 +1,11 @@
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests import util
-from tests.gpu_util import build_network, frame_to_device
+from tests import util   # (golden loader: this is a debugging aid for the tests)
+from occnerf_amd.seeded import build_network, frame_to_device
 from occnerf_amd import synth
 g = util.load_golden('train_amp_s32')
-net, ctx = build_network(0, True, S=32, non_rigid=True)
+net = build_network(0, True, S=32, non_rigid=True)
 net.cfg.perturb = 1.0
 net.train()
 frame = synth.make_frame(img_size=32, pose72=g['meta.pose72'], orbit_frame=7)

@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from occnerf_amd import ops  # noqa: E402
-from tests import util  # noqa: E402
+from oracle import chain as util  # noqa: E402  (weights of the seeded checkpoint as numpy)
 
 
 def timeit(fn, n=3):
@@ -76,8 +76,8 @@ def main():
 def bench_frame_stages():
     """knn variants on the real benchmark frame (needs the whole pipeline up to xyz)."""
     from occnerf_amd import synth
-    from tests.gpu_util import build_network, frame_to_device
-    net, ctx = build_network(0, False, S=128, non_rigid=True)
+    from occnerf_amd.seeded import build_network, frame_to_device
+    net = build_network(0, False, S=128, non_rigid=True)
     frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
     data = frame_to_device(frame, 'cuda:0')
     c = net._context()
@@ -99,8 +99,8 @@ def bench_frame_stages():
 def bench_knn():
     """kNN variants alone on the benchmark frame's canonical sample positions."""
     from occnerf_amd import synth
-    from tests.gpu_util import build_network, frame_to_device
-    net, ctx = build_network(0, False, S=128, non_rigid=True)
+    from occnerf_amd.seeded import build_network, frame_to_device
+    net = build_network(0, False, S=128, non_rigid=True)
     frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
     data = frame_to_device(frame, 'cuda:0')
     grabbed = {}
@@ -135,8 +135,8 @@ def bench_knn():
 def bench_stage(name):
     """Time one pipeline op in isolation on the benchmark frame (inputs grabbed from a real forward)."""
     from occnerf_amd import synth
-    from tests.gpu_util import build_network, frame_to_device
-    net, ctx = build_network(0, False, S=128, non_rigid=True)
+    from occnerf_amd.seeded import build_network, frame_to_device
+    net = build_network(0, False, S=128, non_rigid=True)
     net.cfg.dedup_repeated_samples = '--dedup' in sys.argv      # default: every live sample (17.6 M rows)
     frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
     data = frame_to_device(frame, 'cuda:0')

@@ -27,8 +27,8 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
     from occnerf_amd import synth
     from occnerf_amd.parallel import ShardedRenderer
-    from tests.gpu_util import build_network, FRAME_KEYS
-    net, _ = build_network(seed=0, amplify=True, S=64, non_rigid=True, device=dev)
+    from occnerf_amd.seeded import build_network, FRAME_KEYS
+    net = build_network(seed=0, amplify=True, S=64, non_rigid=True, device=dev)
     frames = []
     for t in range(3):
         f = synth.make_frame(img_size=256, pose72=synth.seeded_pose(1 + t), orbit_frame=10 * t)

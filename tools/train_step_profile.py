@@ -3,9 +3,9 @@ torch-profiler table.  python tools/train_step_profile.py"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
-from tests.gpu_util import build_network, frame_to_device
+from occnerf_amd.seeded import build_network, frame_to_device
 from occnerf_amd import synth
-net, ctx = build_network(0, False, S=128, non_rigid=True)
+net = build_network(0, False, S=128, non_rigid=True)
 net.cfg.perturb = 1.0
 net.cfg.train_precision = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 print('train_precision', net.cfg.train_precision)
