@@ -28,7 +28,11 @@ samples a launch processes.  `dedup`: the same frame with the renderer's default
 bitwise identical samples evaluated once, bit-identical pixels); the headline keeps it OFF so that `value` stays the
 every-live-sample rate of rounds 1-2.  `alt`: the opt-in split-bf16 MLP path.  `train`: BASELINE configs[4], one optimisation
 step (forward + backward + clip + Adam, all HIP kernels) on 6 144 rays x 128 samples in bf16.  `weak_frames`
-(N > 1 only): the round-1 mode, one whole frame per rank per step.
+(N > 1 only): the round-1 mode, one whole frame per rank per step.  `config4` (N = 1): BASELINE configs[3], one 1024x1024 x
+192-sample frame with seeded visibility counts, renderer default and every-live-sample.  `movement` (N = 1): BASELINE
+configs[2]'s sequence on one GPU through the loop run.py executes (occnerf_amd/sequence.py: device ray generation, named
+camera, one frame of lag, device image assembly, uint8 D2H), rays/s over a whole pass.  With N > 1 `config.per_rank_rays` /
+`per_rank_live_samples` show the balance of the shard plan.
 """
 import argparse
 import json
@@ -163,9 +167,82 @@ def train_leg(dev, steps, warmup):
     net.cfg.train_precision = 'auto'
     return {'ms_per_step': dt * 1e3, 'rays_per_step': TRAIN_RAYS, 'samples_per_step': TRAIN_RAYS * SPP,
             'rays_per_s': TRAIN_RAYS / dt, 'dtype': 'bf16 MLP trunks (fp32 accumulate, fp32 master weights); '
-            'fp32 sampler, encoder, aggregation, compositor', 'final_loss': float(loss),
+            'fp32 sampler, encoder, aggregation, compositor', 'final_loss': float(loss.detach()),
             'what': 'forward + backward + clip_grad_norm + Adam, every per-sample stage a HIP kernel '
                     '(occnerf_amd/train_path.py); synthetic target'}
+
+
+def config4_leg(dev, frames=3):
+    """BASELINE configs[3] on one GPU: 1024 x 1024 image, 192 samples/ray, non-rigid on, visibility-weighted aggregation
+    with the seeded visibility pattern of SURVEY 8(d) C4; the frame resident on the device."""
+    from occnerf_amd import synth
+    from occnerf_amd.seeded import build_network, frame_to_device
+    net = build_network(seed=0, amplify=False, S=192, non_rigid=True, device=dev)
+    rng = np.random.RandomState(4)
+    pc = net.point_base.detach().cpu().numpy()
+    cnt = np.where(pc[:, 2] > 0, 1.0, 1.0 + rng.poisson(50, pc.shape[0])).astype(np.float32)
+    with torch.no_grad():
+        net.point_counter.copy_(torch.from_numpy(cnt).to(dev))
+    frame = synth.make_frame(img_size=1024, pose72=synth.seeded_pose(1), orbit_frame=28)
+    data = frame_to_device(frame, dev)
+    R = frame['rays'].shape[1]
+    out = {'workload': 'BASELINE configs[3]: 1024x1024 image, 192 samples/ray, non-rigid on, seeded visibility counts',
+           'rays_per_frame': R, 'samples_per_frame': R * 192}
+    for name, dedup in (('default', True), ('every_live_sample', False)):
+        net.cfg.dedup_repeated_samples = dedup
+        with torch.no_grad():
+            net(**data, iter_val=1e7, ray_order_key='c4')
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                net(**data, iter_val=1e7, ray_order_key='c4')
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / frames
+        out[name] = {'ms_per_frame': dt * 1e3, 'value': R / dt, 'unit': 'rays/s', 'dedup_repeated_samples': dedup}
+    out['peak_mem_GiB'] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    del net, data
+    torch.cuda.empty_cache()
+    return out
+
+
+def movement_leg(net, dev, n_frames=12):
+    """BASELINE configs[2]'s sequence on ONE GPU, through the loop `run.py --type movement` executes
+    (occnerf_amd/sequence.render_sequence): per frame the synthetic source's host work, ray generation on the device,
+    the render with the camera named, device image assembly and the uint8 image copied to pinned host memory (PNG
+    encoding excluded, as in the metric).  A warm pass first (weights packed, kNN layout built); the timed pass starts
+    with empty ray-order / shard-plan caches like a fresh sequence would."""
+    from occnerf_amd.image import assemble_uint8_device
+    from occnerf_amd.parallel import ShardedRenderer
+    from occnerf_amd.sequence import SyntheticFrames, render_sequence
+    loader = SyntheticFrames('movement', img_size=IMG, render_frames=n_frames, device_rays=True)
+    stage = torch.empty(IMG, IMG, 3, dtype=torch.uint8).pin_memory()
+    bg = np.array([1., 1., 1.])
+    out = {'workload': f'BASELINE configs[2] on one GPU: {n_frames} frames of the movement pose walk, 512x512 x 128, '
+                       'device ray generation + render + device image assembly + uint8 D2H per frame',
+           'frames': n_frames}
+    for name, dedup in (('every_live_sample', False), ('default', True)):
+        net.cfg.dedup_repeated_samples = dedup
+        rays = []
+
+        def on_frame(o, meta):
+            img, _ = assemble_uint8_device(meta['width'], meta['height'], meta['ray_index'], bg, o['rgb'], o['alpha'],
+                                           want_alpha=False)
+            stage.copy_(img, non_blocking=True)
+            rays.append(int(meta['ray_index'].numel()))
+        renderer = ShardedRenderer(net, dev, single=True)
+        render_sequence(renderer, loader, 'movement', 1e7, on_frame, dev)          # warm pass
+        torch.cuda.synchronize()
+        rays.clear()
+        net._ray_orders.clear()
+        renderer = ShardedRenderer(net, dev, single=True)
+        t0 = time.perf_counter()
+        render_sequence(renderer, loader, 'movement', 1e7, on_frame, dev)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {'value': sum(rays) / dt, 'unit': 'rays/s', 'ms_per_frame': dt / n_frames * 1e3,
+                     'rays_per_frame_mean': float(np.mean(rays)), 'dedup_repeated_samples': dedup}
+    net.cfg.dedup_repeated_samples = False
+    return out
 
 
 def main():
@@ -202,6 +279,7 @@ def main():
     R = frame['rays'].shape[1]
     host_out = torch.empty(R, 5).pin_memory()
     renderer = ShardedRenderer(net, dev)
+    formed_world = renderer.formed_world_size()
 
     # HIP events around every launch of the dominant kernel, on the stream it is launched on
     mlp_events, real_mlp = [], ops.canonical_mlp
@@ -215,15 +293,34 @@ def main():
         # rows the launch really processes: the device-side live count when the renderer passes one
         mlp_events.append((e0, e1, mlp_in.shape[0] if count is None else count.clone()))
         return out
+    nr_events, real_nr = [], ops.nonrigid_rows
+
+    def timed_nr(xyz, rows, count, *a, **kw):
+        st = torch.cuda.current_stream(xyz.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        out = real_nr(xyz, rows, count, *a, **kw)
+        e1.record(st)
+        nr_events.append((e0, e1))
+        return out
     # The headline evaluates every live sample (the definition of rounds 1-2); the renderer's default also evaluates runs of
     # bitwise identical samples once (cfg.dedup_repeated_samples, bit-identical pixels): reported beside it as `dedup`.
     net.cfg.dedup_repeated_samples = False
-    ops.canonical_mlp = timed_mlp
-    timed_steps(renderer, frame_h, 1, args.warmup, rank, world, dev, ('bench', rank), host_out)   # warm-up (+1 step)
+    ops.canonical_mlp, ops.nonrigid_rows = timed_mlp, timed_nr
+    timed_steps(renderer, frame_h, 1, args.warmup, rank, world, dev, 'bench', host_out)   # warm-up (+1 step)
     mlp_events.clear()
-    dt, step_ms = timed_steps(renderer, frame_h, args.steps, 0, rank, world, dev, ('bench', rank), host_out)
-    main_events = list(mlp_events)
-    ops.canonical_mlp = real_mlp
+    nr_events.clear()
+    dt, step_ms = timed_steps(renderer, frame_h, args.steps, 0, rank, world, dev, 'bench', host_out)
+    main_events, main_nr = list(mlp_events), list(nr_events)
+    ops.canonical_mlp, ops.nonrigid_rows = real_mlp, real_nr
+    # balance of the shard plan: rays and live samples every rank rendered in the last frame (read after the timed region)
+    my_rays, my_live = renderer.shard_stats()
+    per_rank = [[my_rays, my_live if my_live is not None else -1]]
+    if world > 1:
+        mine = torch.tensor(per_rank[0], device=dev, dtype=torch.int64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [t.tolist() for t in allr]
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -234,7 +331,7 @@ def main():
         net.cfg.dedup_repeated_samples = True
         if world > 1:
             dist.barrier()
-        dtd, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, ('bench', rank), host_out)
+        dtd, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
         if world > 1:
             td = torch.tensor([dtd], device=dev, dtype=torch.float64)
             dist.all_reduce(td, op=dist.ReduceOp.MAX)
@@ -254,7 +351,7 @@ def main():
             # opt-in split-bf16 MLP path (cfg.mlp_precision='bf16x3'): same frame, same steps; never part of `value`
             net.cfg.mlp_precision = 'bf16x3'
             net.invalidate_cache()
-            dta, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, ('bench', rank), host_out)
+            dta, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
             side['alt'] = {'mlp_precision': 'bf16x3 (hi/lo bf16 operands, 3 MFMA products, fp32 accumulate; parity-tested '
                                             'to the same 1e-4 pixel gate)', 'value': R * args.steps / dta, 'unit': 'rays/s',
                            'ms_per_step': dta / args.steps * 1e3}
@@ -262,7 +359,7 @@ def main():
             net.invalidate_cache()
             # every sample evaluated (cfg.skip_empty_samples off): same pixels bit for bit
             net.cfg.skip_empty_samples = False
-            dtf, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, ('bench', rank), host_out)
+            dtf, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
             side['all_samples'] = {
                 'skip_empty_samples': False, 'value': R * args.steps / dtf, 'unit': 'rays/s',
                 'ms_per_step': dtf / args.steps * 1e3,
@@ -270,11 +367,15 @@ def main():
                         'sum is exactly 0 (alpha is multiplied by it), with bit-identical rgb/alpha/depth'}
             net.cfg.skip_empty_samples = True
             side['train'] = train_leg(dev, max(5, args.steps // 2), 3)
+            side['movement'] = movement_leg(net, dev)
+            del renderer
+            torch.cuda.empty_cache()
+            side['config4'] = config4_leg(dev)
         else:
             # round-1 mode: one whole frame per rank per step, same-size gather (weak scaling)
             whole = ShardedRenderer(net, dev, single=True)         # every rank renders the full frame by itself
             dist.barrier()
-            dtw, _ = timed_steps(whole, frame_h, max(3, args.steps // 4), 1, rank, 1, dev, ('bench-whole', rank), host_out)
+            dtw, _ = timed_steps(whole, frame_h, max(3, args.steps // 4), 1, rank, 1, dev, 'bench-whole', host_out)
             tw = torch.tensor([dtw], device=dev, dtype=torch.float64)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             n = max(3, args.steps // 4)
@@ -288,6 +389,9 @@ def main():
         avg_ms = float(np.mean(ms))
         achieved = FLOP_PER_SAMPLE_CNL * float(np.mean(nsmp)) / (avg_ms * 1e-3)
         traffic, traffic_src = pmc_traffic(float(np.mean(nsmp)))
+        nr_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in main_nr])) if main_nr else None
+        live = float(np.mean(nsmp))
+        step_s = dt / args.steps
         line = {
             'metric': 'rays/sec at 512x512x128spp, random-init ckpt', 'value': R * args.steps / dt,
             'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -304,16 +408,27 @@ def main():
                        'samples_evaluated_per_launch': float(np.mean(nsmp)),
                        'skip_empty_samples': bool(net.cfg.get('skip_empty_samples', True)),
                        'dedup_repeated_samples': False,
-                       'world_size_formed': renderer.formed_world_size(), 'backend': backend if world > 1 else None,
-                       'parallelism': f'one frame, rays sharded x{world} in 4096-ray chunks, async RCCL gather to rank 0 '
-                                      'overlapped with the next frame'},
+                       'world_size_formed': formed_world, 'backend': backend if world > 1 else None,
+                       'per_rank_rays': [p[0] for p in per_rank],
+                       'per_rank_live_samples': [p[1] for p in per_rank],
+                       'parallelism': f'one frame, its Morton walk dealt to {world} rank(s) in 256-ray blocks, async RCCL gather '
+                                      'to rank 0 overlapped with the next frame'},
             'roofline': {'bound': 'mfma', 'kernel': 'occ::m16::canonical_mlp_lds_kernel (fp32 MFMA 16x16x4, LDS-staged weights)',
                          'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA, 'traffic': traffic,
                          'traffic_note': f'HBM bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/{traffic_src}; '
                                          'algorithmic 288 B/sample',
                          'launch_ms': avg_ms, 'launches_timed': len(ms),
-                         'flop_per_launch': FLOP_PER_SAMPLE_CNL * float(np.mean(nsmp))},
+                         'flop_per_launch': FLOP_PER_SAMPLE_CNL * float(np.mean(nsmp)),
+                         # the second MFMA kernel of the frame (rank 0's launches): algorithmic 200 704 FLOP per live sample
+                         # (91 520 MAC = 183 040 FLOP executed after folding the 69 per-frame condition inputs into a bias)
+                         'nonrigid': None if nr_ms is None else {
+                             'kernel': 'occ::nr16::nonrigid_lds_kernel', 'launch_ms': nr_ms,
+                             'achieved_algorithmic': FLOP_PER_SAMPLE_NR * live / (nr_ms * 1e-3) / 1e12,
+                             'frac_algorithmic': FLOP_PER_SAMPLE_NR * live / (nr_ms * 1e-3) / PEAK_FP32_MFMA,
+                             'frac_executed': 183040 * live / (nr_ms * 1e-3) / PEAK_FP32_MFMA},
+                         # whole step: canonical + non-rigid algorithmic FLOP of the samples rank 0 evaluated / step time
+                         'end_to_end_frac': (FLOP_PER_SAMPLE_CNL + FLOP_PER_SAMPLE_NR) * live / step_s / PEAK_FP32_MFMA},
         }
         line.update(side)
         if world == 1 and not args.no_cpu_baseline:

@@ -353,6 +353,27 @@ class Network(nn.Module):
         them by value (ops.host_float3: no copy for host arrays, one per tensor object for device tensors)."""
         return ops.host_float3(v)
 
+    @torch.no_grad()
+    def live_samples_per_ray(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None,
+                             near=None, far=None, iter_val=1e7, **kwargs):
+        """Number of samples with a non-zero motion-weight sum on each of the given rays (int64 [n], on the device, no
+        host round trip): the per-frame preamble and the sampler/warp kernel only -- what a frame costs per ray, since
+        every later stage runs on the live samples.  occnerf_amd/parallel.py probes a sixteenth of a frame's rays with it
+        to deal rays to GPUs by cost."""
+        cfg, dev = self.cfg, self.point_base.device
+        f32 = lambda t: t.detach().float().contiguous().to(dev)          # noqa: E731
+        wc = self._weight_constants()
+        refine = iter_val >= cfg.pose_decoder.get('kick_in_iter', 0)
+        Rs, Ts = ops.pose_motion_bases(self.pose_decoder, f32(dst_posevec).reshape(-1), refine, f32(dst_Rs), f32(dst_Ts),
+                                       f32(cnl_gtfms))
+        vol = ops.prior_softmax(wc['dec'], f32(motion_weights_priors))
+        rays8 = ops.pack_rays(f32(rays).reshape(2, -1, 3), f32(near).reshape(-1), f32(far).reshape(-1), None)
+        S = int(cfg.N_samples)
+        t_vals = torch.linspace(0., 1., steps=S, device=dev)
+        _, _, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, self._host3(kwargs['cnl_bbox_min_xyz']),
+                                        self._host3(kwargs['cnl_bbox_scale_xyz']))
+        return (mask.view(-1, S) != 0).sum(dim=1)
+
     def forward(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None,
                 near=None, far=None, iter_val=1e7, **kwargs):
         cfg = self.cfg

@@ -27,6 +27,7 @@ import torch.distributed as dist
 from .rayorder import ray_patch_order
 
 BLOCK = 256          # rays per dealt block: 4 kNN tiles, a ~16x16 pixel patch
+PROBE_STRIDE = 16     # the cost of a block is estimated from every 16th ray of the walk
 WIDTH_QUANTUM = 4096  # buffers are sized in multiples of this many rays so that frames of a sequence share them
 
 
@@ -101,12 +102,15 @@ class _Pending:
 class ShardedRenderer:
     """Renders frames with their rays sharded over the ranks of `group` (see the module docstring)."""
 
-    def __init__(self, net, device, group=None, block=BLOCK, channels=5, single=False, morton=True, chunk=None):
+    def __init__(self, net, device, group=None, block=BLOCK, channels=5, single=False, morton=True, chunk=None,
+                 balance=True):
         """single: ignore the process group, this process renders whole frames by itself.  morton=False deals the
-        caller's own ray order.  chunk: older name of `block`."""
+        caller's own ray order.  balance=False: static dealing (block b -> rank b % N) even when the network can
+        estimate block costs.  chunk: older name of `block`."""
         self.net, self.device, self.group, self.channels = net, torch.device(device), group, channels
         self.block = int(chunk if chunk is not None else block)
         self.morton = bool(morton)
+        self.balance = bool(balance)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() and not single else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         # gloo has no gather on device tensors: with that backend (tests: several processes sharing one GPU) the blocks
@@ -122,40 +126,82 @@ class ShardedRenderer:
         return self.world
 
     # ------------------------------------------------------------------ plans and buffers
-    def _build_plan(self, rays):
+    def _block_costs(self, data, order, nb_full):
+        """Estimated cost of every full block of the walk: live samples on 16 of its rays (`Network.live_samples_per_ray`:
+        the frame's preamble + the sampler/warp kernel on a sixteenth of the rays, ~0.3 ms for a 512^2 frame).  Every rank
+        computes the same numbers from the same frame.  None when the network cannot tell (the plan is then static)."""
+        probe = getattr(self.net, 'live_samples_per_ray', None)
+        B = self.block
+        if probe is None or not self.balance or nb_full < 2 * self.world or B % PROBE_STRIDE:
+            return None
+        per = B // PROBE_STRIDE
+        p = (torch.arange(nb_full * per, device=order.device) * PROBE_STRIDE + PROBE_STRIDE // 2)
+        idx = order[p]
+        sub = {k: v for k, v in data.items() if k not in ('rays', 'near', 'far')}
+        live = probe(rays=data['rays'][:, idx], near=data['near'].reshape(-1, 1)[idx], far=data['far'].reshape(-1, 1)[idx], **sub)
+        return live.view(nb_full, per).sum(dim=1).to(order.device)      # (host frames: one read per plan)
+
+    def _build_plan(self, data):
+        rays = data['rays']
         R, W, B = int(rays.shape[1]), self.world, self.block
-        sizes = shard_sizes(R, W, B)
-        plan = {'R': R, 'sizes': sizes, 'width': -(-max(max(sizes), 1) // WIDTH_QUANTUM) * WIDTH_QUANTUM}
+        nb_full, tail = divmod(R, B)
+        nb = nb_full + (1 if tail else 0)
         if W == 1:
-            return plan
+            return {'R': R, 'sizes': [R], 'width': -(-max(R, 1) // WIDTH_QUANTUM) * WIDTH_QUANTUM}
         where = rays.device
-        order = ray_patch_order(rays[1]) if self.morton else None             # [R] walk position -> ray index
-        pos = shard_positions(R, self.rank, W, B, device=where)
-        mine = order[pos] if order is not None else pos
-        plan['mine'] = {where.type: mine}
+        order = ray_patch_order(rays[1]) if self.morton else torch.arange(R, device=where)   # [R] walk position -> ray index
+        cost = self._block_costs(data, order, nb_full) if self.morton else None
+        serp = cost is not None
+        # Dealing position s of a block: its index in the walk (static plan), or its place in the descending order of the
+        # estimated costs (cost-aware plan; the partial tail block always last).  Position s goes to rank s % W -- every
+        # second round of W positions reversed in the cost-aware plan ("serpentine": ranks 0..W-1, W-1..0, ...), so that
+        # every rank receives one block of each cost stratum and the sums even out -- and is that rank's slot s // W.
+
+        def rank_of(sv):
+            r = sv % W
+            return torch.where((torch.div(sv, W, rounding_mode='floor') % 2) == 1, W - 1 - r, r) if serp else r
+        slots = [0] * W
+        for sv in range(nb):                                          # host arithmetic: a few hundred blocks
+            r = sv % W
+            slots[(W - 1 - r) if serp and (sv // W) % 2 else r] += 1
+        last = (nb - 1) % W
+        tail_rank = ((W - 1 - last) if serp and ((nb - 1) // W) % 2 else last) if tail else -1
+        sizes = [slots[r] * B - ((B - tail) if r == tail_rank else 0) for r in range(W)]
+        plan = {'R': R, 'sizes': sizes, 'width': -(-max(max(sizes), 1) // WIDTH_QUANTUM) * WIDTH_QUANTUM, 'cost_aware': serp}
+        if serp:
+            by_cost = torch.argsort(cost, descending=True, stable=True)                       # s -> block
+            if tail:
+                by_cost = torch.cat([by_cost, torch.tensor([nb_full], device=where)])
+            spos = torch.empty_like(by_cost)
+            spos[by_cost] = torch.arange(nb, device=where)                                    # block -> s
+        else:
+            by_cost = spos = torch.arange(nb, device=where)
+        me = self.rank
+        j = torch.arange(slots[me], device=where)
+        s_mine = j * W + ((torch.where(j % 2 == 1, W - 1 - me, me)) if serp else me)
+        i = torch.arange(sizes[me], device=where)
+        pos = by_cost[s_mine][torch.div(i, B, rounding_mode='floor')] * B + i % B              # walk positions of my rays
+        plan['mine'] = {where.type: order[pos]}
         if self.rank == 0:
             # row of the concatenated [world * width] receive buffer that holds walk position p, then per ray index
             p = torch.arange(R, device=where)
-            blk = torch.div(p, B, rounding_mode='floor')
-            dest = (blk % W) * plan['width'] + torch.div(blk, W, rounding_mode='floor') * B + p % B
-            if order is not None:
-                src = torch.empty_like(dest)
-                src[order] = dest
-            else:
-                src = dest
+            sv = spos[torch.div(p, B, rounding_mode='floor')]
+            dest = rank_of(sv) * plan['width'] + torch.div(sv, W, rounding_mode='floor') * B + p % B
+            src = torch.empty_like(dest)
+            src[order] = dest
             plan['unpermute'] = src.to(self.device)
         return plan
 
-    def _get_plan(self, rays, key):
-        R = int(rays.shape[1])
+    def _get_plan(self, data, key):
+        R = int(data['rays'].shape[1])
         if key is None and self.world > 1 and self.morton:
-            return self._build_plan(rays)                         # unnamed camera: the walk is recomputed for this frame
+            return self._build_plan(data)                         # unnamed camera: the walk is recomputed for this frame
         k = (R, key)
         hit = self._plans.get(k)
         if hit is None:
             if len(self._plans) >= 16:                            # a sequence's frames differ in ray count: keep a few plans
                 self._plans.pop(next(iter(self._plans)))
-            hit = self._plans[k] = self._build_plan(rays)
+            hit = self._plans[k] = self._build_plan(data)
         return hit
 
     def _mine(self, plan, dev_type):
@@ -189,7 +235,7 @@ class ShardedRenderer:
         key and ray count reuse the shard plan (and, inside `Network`, the Morton order of the shard)."""
         rays = data['rays']
         R = int(rays.shape[1])
-        plan = self._get_plan(rays, ray_order_key)
+        plan = self._get_plan(data, ray_order_key)
         bufs = self._get_bufs(plan['width'])
         slot = self._turn = self._turn ^ 1
         n_mine = plan['sizes'][self.rank]

@@ -437,6 +437,9 @@ def posed_joints(pose72, tjoints):
     return G[:, :3, 3].astype('float32')
 
 
+_PRIOR_CACHE = {}
+
+
 def make_frame(img_size=512, pose72=None, orbit_frame=0, orbit_period=100,
                bgcolor=(255.0, 255.0, 255.0), betas=None, bbox_offset=0.3, volume_size=32,
                rotate_axis='y', with_rays=True):
@@ -467,8 +470,15 @@ def make_frame(img_size=512, pose72=None, orbit_frame=0, orbit_period=100,
                     'dst_bbox_max': dst_bbox['max_xyz']}
 
     dst_Rs, dst_Ts = body_pose_to_body_RTs(pose, cjoints)
-    prior = approx_gaussian_bone_volumes(cjoints, cbbox['min_xyz'], cbbox['max_xyz'],
-                                         grid_size=volume_size).astype('float32')
+    # the prior depends on the canonical skeleton only: the reference's datasets build it once per subject
+    # (freeview.py:49-55), not per frame
+    pkey = (cjoints.tobytes(), float(bbox_offset), int(volume_size))
+    prior = _PRIOR_CACHE.get(pkey)
+    if prior is None:
+        if len(_PRIOR_CACHE) >= 4:
+            _PRIOR_CACHE.clear()
+        prior = _PRIOR_CACHE[pkey] = approx_gaussian_bone_volumes(cjoints, cbbox['min_xyz'], cbbox['max_xyz'],
+                                                                  grid_size=volume_size).astype('float32')
     mn, mx = cbbox['min_xyz'].astype('float32'), cbbox['max_xyz'].astype('float32')
     return {
         'img_width': img_size, 'img_height': img_size, **ray_part,

@@ -23,10 +23,7 @@ from core.data import create_dataloader  # noqa: E402
 from core.nets import create_network  # noqa: E402
 from occnerf_amd.image import ImageWriter, assemble_uint8_device  # noqa: E402
 from occnerf_amd.parallel import ShardedRenderer  # noqa: E402
-from occnerf_amd.rays import frame_rays  # noqa: E402
-
-EXCLUDE_KEYS_TO_GPU = ['frame_name', 'img_width', 'img_height', 'ray_mask',
-                       'camera_K', 'camera_E', 'dst_bbox_min', 'dst_bbox_max']
+from occnerf_amd.sequence import frames_to_device, render_sequence  # noqa: E402
 
 
 def load_network(model):
@@ -47,38 +44,21 @@ def load_network(model):
 
 
 def _init_ranks():
-    """One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE); a plain launch is world 1."""
+    """One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE); a plain launch is world 1.
+    OCC_DIST_BACKEND=gloo OCC_FORCE_DEVICE=0 (tests): several ranks share one GPU and exchange through the host -- RCCL
+    refuses two ranks per device; everything but the collective itself is then the production path."""
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(int(os.environ.get('OCC_FORCE_DEVICE', os.environ.get('LOCAL_RANK', 0))))
     if world > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', rank=rank, world_size=world,
-                                             device_id=torch.device('cuda', torch.cuda.current_device()))
+        backend = os.environ.get('OCC_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', rank=rank, world_size=world,
+                                                 device_id=torch.device('cuda', torch.cuda.current_device()))
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
-
-
-def _frames(loader, data_type, dev):
-    """The loader's frames as (renderer inputs, camera key, bookkeeping): tensors on the device (asynchronously), the three
-    float[3] constants by value, the ray batch generated on the GPU when cfg.device_rays."""
-    host_keys = ('bgcolor', 'cnl_bbox_min_xyz', 'cnl_bbox_max_xyz', 'cnl_bbox_scale_xyz')   # float[3]: taken by value
-    for idx, batch in enumerate(loader):
-        batch = {k: (v[0] if torch.is_tensor(v) or isinstance(v, list) else v) for k, v in batch.items()}
-        data = {k: (v if k in host_keys else v.cuda(non_blocking=True)) for k, v in batch.items()
-                if k not in EXCLUDE_KEYS_TO_GPU and torch.is_tensor(v)}
-        if 'rays' not in batch:          # cfg.device_rays: the ray batch is generated on the GPU (occnerf_amd/rays.py)
-            fr = frame_rays(batch['camera_K'].numpy(), batch['camera_E'].numpy(), int(batch['img_height']),
-                            int(batch['img_width']), batch['dst_bbox_min'].numpy(), batch['dst_bbox_max'].numpy(),
-                            'cuda')
-            data.update(rays=fr['rays'], near=fr['near'], far=fr['far'])
-            ray_index = torch.nonzero(fr['ray_mask']).squeeze(1)
-        else:                            # host mask: the index list is formed on the host, no device round trip
-            ray_index = torch.nonzero(batch['ray_mask']).squeeze(1).cuda(non_blocking=True)
-        # a movement sequence is shot by one camera: the Morton walk of the rays (shard plan, render order) is computed
-        # once per ray count
-        key = ('movement', int(ray_index.numel())) if data_type == 'movement' else None
-        yield data, key, {'idx': idx, 'ray_index': ray_index, 'width': int(batch['img_width']),
-                          'height': int(batch['img_height'])}
 
 
 def _setup(data_type, **loader_kw):
@@ -110,10 +90,7 @@ def _render(data_type, folder_name):
     torch.cuda.synchronize()
     t_wall0 = time.perf_counter()
 
-    def deliver(pending, meta):
-        out = renderer.finish(pending)
-        if out is None:                               # ranks > 0: their rays went to rank 0
-            return
+    def on_frame(out, meta):                           # rank 0 only
         rgb_img, alpha_img = assemble_uint8_device(meta['width'], meta['height'], meta['ray_index'],
                                                    np.array(cfg.bgcolor) / 255., out['rgb'], out['alpha'],
                                                    want_alpha=bool(cfg.show_alpha))
@@ -127,15 +104,7 @@ def _render(data_type, folder_name):
             torch.cuda.synchronize()
             stats['first_s'], stats['first_rays'] = time.perf_counter() - t_wall0, int(meta['ray_index'].numel())
 
-    prev = None
-    with torch.no_grad():
-        for data, key, meta in _frames(loader, data_type, dev):
-            cur = renderer.submit(data, iter_val=cfg.eval_iter, ray_order_key=key)
-            if prev is not None:
-                deliver(*prev)
-            prev = (cur, meta)
-        if prev is not None:
-            deliver(*prev)
+    render_sequence(renderer, loader, data_type, cfg.eval_iter, on_frame, dev)
     if rank != 0:
         _finish_ranks(rank, world)
         return
@@ -193,7 +162,7 @@ def run_evaluate():
     teach = ShardedRenderer(teacher, dev)
     psnrs, skips = [], [4, 15]
     with torch.no_grad():
-        for data, key, meta in _frames(loader, 'progress', dev):
+        for data, key, meta in frames_to_device(loader, 'progress', dev):
             if meta['idx'] in skips:
                 continue
             target = teach.finish(teach.submit(data, iter_val=cfg.eval_iter))

@@ -1170,7 +1170,7 @@ def test_two_rank_sharded_render_over_rccl():
 
 def test_two_process_sharded_render_one_gpu():
     """The sharded renderer with the real network and TWO ranks on this one GPU (RCCL refuses two ranks per device, so
-    the blocks travel through the host with gloo): shard plans, 1 024-ray chunk dealing, buffer slots, the one-frame
+    the blocks travel through the host with gloo): shard plans, 256-ray Morton-block dealing, buffer slots, the one-frame
     lag of the pipelined gather and the un-permutation are the production code; three frames must be bit-identical to
     rank 0 rendering them alone."""
     got = _torchrun(['tools/sharded_check.py'], 2, extra_env={'OCC_DIST_BACKEND': 'gloo', 'OCC_FORCE_DEVICE': '0'})
@@ -1181,3 +1181,78 @@ def test_two_process_sharded_render_one_gpu():
                      extra_env={'OCC_DIST_BACKEND': 'gloo', 'OCC_FORCE_DEVICE': '0'})
     assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['world_size_formed'] == 2
     assert line['value'] > 0 and line['weak_frames']['value'] > 0
+
+
+def test_config3_movement_sequence(tmp_path, oracle):
+    """BASELINE configs[2]: the movement sequence (frames of the pose walk seen by one camera, create_dataset.py:28-33,
+    run.py:137-186) at 512x512 x 128 samples through `run.py --type movement` itself -- device-generated rays, named
+    camera, sharded renderer with one frame of lag, device image assembly, PNG writer:
+      * one process, and two ranks (torchrun; gloo on this one GPU) write byte-identical images;
+      * the same frames rendered in this process reproduce those images byte for byte;
+      * 96 rays of every frame against the full CPU oracle within the BASELINE gate of 1e-4."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from occnerf_amd import synth
+    from occnerf_amd.image import assemble_uint8_device
+    from occnerf_amd.rays import frame_rays
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_frames, size, spp = 4, 512, 128
+    cli = ['--cfg', os.path.join(root, 'configs/occnerf/synthetic/occnerf.yaml'), '--type', 'movement', 'render_frames',
+           str(n_frames), 'render_size', str(size), 'N_samples', str(spp)]
+    one, two = tmp_path / 'one', tmp_path / 'two'
+    one.mkdir()
+    two.mkdir()
+    env = {**os.environ, 'PYTHONPATH': root, 'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
+    subprocess.check_call([sys.executable, os.path.join(root, 'run.py')] + cli, cwd=str(one), env=env)
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
+                           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'run.py')] + cli, cwd=str(two),
+                          env={**env, 'OCC_DIST_BACKEND': 'gloo', 'OCC_FORCE_DEVICE': '0'}, timeout=900)
+    sub = os.path.join('experiments', 'occnerf', 'synthetic', 'capsule_body', 'occnerf', 'seeded', 'movement')
+    imgs = []
+    for t in range(n_frames):
+        a = np.asarray(Image.open(one / sub / f'{t:06d}.png'))
+        b = np.asarray(Image.open(two / sub / f'{t:06d}.png'))
+        assert a.shape == (size, size, 3) and np.array_equal(a, b), t
+        imgs.append(a)
+    assert len({im.tobytes() for im in imgs}) >= 3                       # the body really moves
+
+    net, ctx = build_network(seed=0, amplify=False, S=spp, non_rigid=True)
+    for t in range(n_frames):
+        f = synth.make_frame(img_size=size, pose72=synth.movement_pose(t, n_frames), orbit_frame=0,
+                             orbit_period=n_frames, bgcolor=[255., 255., 255.], with_rays=False)
+        fr = frame_rays(f['camera_K'], f['camera_E'], size, size, f['dst_bbox_min'], f['dst_bbox_max'], DEV)
+        data = {k: T(f[k]) for k in ('dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec')}
+        data.update(rays=fr['rays'], near=fr['near'], far=fr['far'], bgcolor=f['bgcolor'],
+                    cnl_bbox_min_xyz=f['cnl_bbox_min_xyz'], cnl_bbox_scale_xyz=f['cnl_bbox_scale_xyz'])
+        R = int(fr['rays'].shape[1])
+        with torch.no_grad():
+            out = net(**data, iter_val=1e7, ray_order_key=('movement', R))
+        ray_index = torch.nonzero(fr['ray_mask']).squeeze(1)
+        img, _ = assemble_uint8_device(size, size, ray_index, np.array([1., 1., 1.]), out['rgb'], out['alpha'],
+                                       want_alpha=False)
+        assert np.array_equal(img.cpu().numpy(), imgs[t]), t
+        sel = np.sort(np.random.RandomState(t).choice(R, 96, replace=False))
+        frame = dict(f)
+        rays_h = fr['rays'].cpu().numpy()
+        frame['rays'], frame['near'], frame['far'] = rays_h[:, sel], fr['near'].cpu().numpy()[sel], fr['far'].cpu().numpy()[sel]
+        want = stagewise_oracle_render(None, ctx, frame=frame, S=spp, non_rigid=True)
+        for k in ('rgb', 'alpha', 'depth'):
+            err = np.abs(out[k].cpu().numpy()[sel] - want[k]).max()
+            assert err <= 1e-4, (t, k, err)
+        assert float(out['alpha'].max()) > 0.05
+
+
+def test_two_process_sharded_movement_at_size():
+    """configs[2] at 512x512 x 128: three movement frames with device-generated rays and a named camera, rays sharded
+    over two ranks (this one GPU, gloo), bit-identical to one rank rendering them alone."""
+    got = _torchrun(['tools/sharded_check.py', '--kind', 'movement', '--size', '512', '--spp', '128', '--frames', '3'], 2,
+                    extra_env={'OCC_DIST_BACKEND': 'gloo', 'OCC_FORCE_DEVICE': '0'})
+    assert got['world_size_formed'] == 2 and got['kind'] == 'movement' and got['size'] == 512 and got['spp'] == 128
+    assert got['bit_identical'] and got['max_abs_diff'] == 0.0, got
+    assert min(got['rays']) > 100000

@@ -102,7 +102,7 @@ def test_morton_plan_matches_positions():
     for rank in range(W):
         r = ShardedRenderer(None, 'cpu', block=B, single=True)
         r.world, r.rank = W, rank                                    # plan arithmetic only: no process group needed
-        plan = r._build_plan(rays)
+        plan = r._build_plan({'rays': rays})
         mine = plan['mine']['cpu']
         want = torch.cat([order[b * B:(b + 1) * B] for b in range(rank, -(-R // B), W)])
         assert torch.equal(mine, want) and mine.numel() == plan['sizes'][rank]
@@ -114,6 +114,45 @@ def test_morton_plan_matches_positions():
     for rank, mine in enumerate(seen):
         recv[rank * width:rank * width + mine.numel()] = mine         # each rank sends "its ray ids"
     assert torch.equal(recv[unperm], torch.arange(R))
+
+
+def test_cost_aware_plan_balances_live_samples():
+    """When the network can estimate what a ray costs (Network.live_samples_per_ray: live samples on a probe of the
+    rays), blocks are dealt in descending cost order, serpentine: every ray still exactly once, ray counts within one
+    block, and the cost per rank far closer than the static deal on a frame whose cost is concentrated in one region."""
+    from occnerf_amd.parallel import ShardedRenderer
+    g = torch.Generator().manual_seed(2)
+    R, W, B = 40000 + 77, 8, 256
+    rays = torch.randn(2, R, 3, generator=g) * 0.2
+    rays[1] += torch.tensor([0., 0., 4.])
+    true_cost = (100 * torch.exp(-((rays[1, :, 0] - 0.3) ** 2 + rays[1, :, 1] ** 2) / 0.05)).long() + 1   # a hot blob
+
+    class CostNet:
+        def live_samples_per_ray(self, rays, near, far, **_):
+            return (100 * torch.exp(-((rays[1, :, 0] - 0.3) ** 2 + rays[1, :, 1] ** 2) / 0.05)).long() + 1
+    data = {'rays': rays, 'near': torch.zeros(R, 1), 'far': torch.ones(R, 1)}
+    result = {}
+    for balance in (False, True):
+        parts, sums = [], []
+        for rank in range(W):
+            r = ShardedRenderer(CostNet(), 'cpu', block=B, single=True, balance=balance)
+            r.world, r.rank = W, rank
+            plan = r._build_plan(data)
+            assert plan['cost_aware'] == balance
+            mine = plan['mine']['cpu']
+            assert mine.numel() == plan['sizes'][rank]
+            parts.append(mine)
+            sums.append(float(true_cost[mine].sum()))
+            if rank == 0:
+                unperm, width, sizes = plan['unpermute'], plan['width'], plan['sizes']
+        assert torch.equal(torch.cat(parts).sort().values, torch.arange(R))
+        assert max(sizes) - min(sizes) <= B
+        recv = torch.full((W * width,), -1, dtype=torch.long)
+        for rank, mine in enumerate(parts):
+            recv[rank * width:rank * width + mine.numel()] = mine
+        assert torch.equal(recv[unperm], torch.arange(R))
+        result[balance] = max(sums) / (sum(sums) / W)
+    assert result[True] <= 1.02 < result[False], result
 
 
 def _free_port():
@@ -134,6 +173,9 @@ def _gloo_worker(rank, world, port, n_rays, q):
         def __call__(self, rays, near, far, iter_val=0, **_):
             o = rays[0]
             return {'rgb': o * 2.0, 'alpha': near[:, 0] + 1.0, 'depth': far[:, 0] * 3.0}
+
+        def live_samples_per_ray(self, rays, near, far, **_):      # cost estimate -> the cost-aware (serpentine) plan
+            return (rays[1, :, 0] * 50).long() + 1
     g = torch.Generator().manual_seed(0)
     data = {'rays': torch.rand(2, n_rays, 3, generator=g), 'near': torch.rand(n_rays, 1, generator=g),
             'far': torch.rand(n_rays, 1, generator=g)}

@@ -1,5 +1,7 @@
-"""Run under torchrun on >= 2 GPUs: three 256x256x64 frames rendered with their rays sharded over the ranks (RCCL gather,
-pipelined) must equal, bit for bit, the same frames rendered by rank 0 alone.  Prints one JSON line.
+"""Run under torchrun on >= 2 GPUs: frames rendered with their rays sharded over the ranks (RCCL gather, pipelined) must
+equal, bit for bit, the same frames rendered by rank 0 alone.  Prints one JSON line.  Default: three 256x256x64 free-view
+frames of different poses (host frames); `--kind movement --size 512 --spp 128 --frames 3` = BASELINE configs[2]: frames of
+the movement pose walk from one camera, rays generated on the device, camera named (cached shard plans).
 With OCC_DIST_BACKEND=gloo OCC_FORCE_DEVICE=0 the ranks share one GPU and exchange through the host (RCCL refuses two
 ranks on one device): everything but the collective itself is then the production code path.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tools/sharded_check.py
@@ -15,6 +17,13 @@ import torch.distributed as dist  # noqa: E402
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--kind', default='freeview', choices=['freeview', 'movement'])
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--spp', type=int, default=64)
+    ap.add_argument('--frames', type=int, default=3)
+    args = ap.parse_args()
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
     local = int(os.environ.get('OCC_FORCE_DEVICE', local))        # experiment: several ranks on one GPU
     torch.cuda.set_device(local)
@@ -28,13 +37,21 @@ def main():
     from occnerf_amd import synth
     from occnerf_amd.parallel import ShardedRenderer
     from occnerf_amd.seeded import build_network, FRAME_KEYS
-    net = build_network(seed=0, amplify=True, S=64, non_rigid=True, device=dev)
+    net = build_network(seed=0, amplify=True, S=args.spp, non_rigid=True, device=dev)
     frames = []
-    for t in range(3):
-        f = synth.make_frame(img_size=256, pose72=synth.seeded_pose(1 + t), orbit_frame=10 * t)
-        frames.append({k: torch.from_numpy(np.ascontiguousarray(f[k])) for k in FRAME_KEYS})
+    for t in range(args.frames):
+        if args.kind == 'freeview':
+            f = synth.make_frame(img_size=args.size, pose72=synth.seeded_pose(1 + t), orbit_frame=10 * t)
+            frames.append({k: torch.from_numpy(np.ascontiguousarray(f[k])) for k in FRAME_KEYS})
+        else:
+            from occnerf_amd.rays import frame_rays
+            f = synth.make_frame(img_size=args.size, pose72=synth.movement_pose(t, args.frames), with_rays=False)
+            fr = frame_rays(f['camera_K'], f['camera_E'], args.size, args.size, f['dst_bbox_min'], f['dst_bbox_max'], dev)
+            d = {k: torch.from_numpy(np.ascontiguousarray(f[k])).to(dev) for k in FRAME_KEYS if k in f}
+            d.update(rays=fr['rays'], near=fr['near'], far=fr['far'])
+            frames.append((d, ('movement', int(fr['rays'].shape[1]))))
     with torch.no_grad():
-        sharded = list(ShardedRenderer(net, dev, chunk=1024).render_frames(frames))
+        sharded = list(ShardedRenderer(net, dev).render_frames(frames))
         ok, worst = True, 0.0
         if rank == 0:
             alone = list(ShardedRenderer(net, dev, single=True).render_frames(frames))
@@ -43,7 +60,8 @@ def main():
                     ok = ok and torch.equal(a[k], b[k])
                     worst = max(worst, float((a[k] - b[k]).abs().max()))
             print(json.dumps({'world_size_formed': dist.get_world_size(), 'backend': backend, 'frames': len(frames), 'bit_identical': bool(ok),
-                              'max_abs_diff': worst, 'rays': [int(f['rays'].shape[1]) for f in frames]}))
+                              'max_abs_diff': worst, 'kind': args.kind, 'size': args.size, 'spp': args.spp,
+                              'rays': [int((f[0] if isinstance(f, tuple) else f)['rays'].shape[1]) for f in frames]}))
     dist.barrier()
     dist.destroy_process_group()
 
