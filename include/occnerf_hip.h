@@ -40,7 +40,11 @@ const char *occnerf_last_error(void);
  *    (prototypes gridencoder.h:12-15, kernels gridencoder.cu:87-369,506-645).
  *    Argument order and meaning are the reference's; at::Tensor -> pointer, and the
  *    trailing stream is new (the reference launches on the legacy default stream).
- *    D in {2,3,4,5}, C in {1,2,4,8}, fp32 embeddings (the dtype the path uses).
+ *    D in {2,3,4,5}, C in {1,2,4,8}.  The reference dispatches on the tensors' dtype
+ *    (AT_DISPATCH_FLOATING_TYPES_AND_HALF, gridencoder.cu:467,500); a C ABI has no tensor to
+ *    ask, so the dtype is in the entry point's name: no suffix = float32 (what the rendering
+ *    path uses), _f16 = at::Half (what grid.py:44-45 feeds under autocast).  float64 is not
+ *    built (nothing on the path produces double embeddings).
  * ---------------------------------------------------------------------------------- */
 
 /* inputs[B,D] in [0,1] (rows outside -> zeros); embeddings[sO,C]; offsets[L+1] int32;
@@ -82,6 +86,20 @@ int occnerf_grid_encode_backward_h(const float *grad, const float *inputs, const
                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                    const float *dy_dx, float *grad_inputs, uint32_t gridtype, int align_corners,
                                    uint32_t interp, void *scratch, int64_t scratch_bytes, void *stream);
+
+/* The at::Half dispatch case of the two operators above (gridencoder.cu:467,500).  embeddings, outputs, dy_dx, grad,
+ * grad_embeddings, grad_inputs are IEEE binary16 arrays (torch.half); inputs stay float32, as in the reference
+ * (`const float *inputs`, gridencoder.cu:373).  Arithmetic follows c10::Half exactly: cell position and corner weights in
+ * float, every `scalar_t +=` a half-rounded term added in float and rounded to half (occnerf_amd/csrc/grid_encode_f16.hip
+ * spells it out); the backward adds channel pairs with packed-half atomics (gridencoder.cu:323-331), so C must be even
+ * there -- the reference's own C = 1 half path is an empty stub (:22-26) and grid.py:44 never selects it. */
+int occnerf_grid_encode_forward_f16(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs,
+                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx,
+                                    uint32_t gridtype, int align_corners, uint32_t interp, void *stream);
+int occnerf_grid_encode_backward_f16(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,
+                                     void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                     uint32_t H, const void *dy_dx, void *grad_inputs, uint32_t gridtype, int align_corners,
+                                     uint32_t interp, void *stream);
 
 /* Total-variation gradient, gridencoder.cu:506-645.  Never called by the reference's
  * trainer; exported for interface completeness and

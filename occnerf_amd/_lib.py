@@ -25,6 +25,10 @@ SIGNATURES = {
                                                  _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grid_encode_backward_h': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
                                                   _u32, _vp, _vp, _u32, C.c_int, _u32, _vp, _i64, _vp]),
+    'occnerf_grid_encode_forward_f16': (C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32,
+                                                   _vp, _u32, C.c_int, _u32, _vp]),
+    'occnerf_grid_encode_backward_f16': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
+                                                    _u32, _vp, _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grad_total_variation': (C.c_int, [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32,
                                                 _u32, _u32, C.c_int, _vp]),
     'occnerf_sample_warp': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,

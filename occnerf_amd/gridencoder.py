@@ -48,9 +48,11 @@ _interp_to_id = {'linear': 0, 'smoothstep': 1}
 
 class _GridEncode(Function):
     """grid.py:24-90: forward writes [L,B,C] and returns [B, L*C]; backward scatters into the
-    embedding gradient (fp32 atomics) and, when inputs need it, contracts with dy_dx."""
+    embedding gradient (atomics) and, when inputs need it, contracts with dy_dx.  Under autocast the
+    embeddings (and with them outputs and gradients) are torch.half, inputs stay float (grid.py:42-45)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda')
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution,
                 calc_grad_inputs=False, gridtype=0, align_corners=False, interpolation=0):
         inputs = inputs.contiguous()
@@ -59,6 +61,10 @@ class _GridEncode(Function):
         Cc = embeddings.shape[1]
         S = float(np.log2(per_level_scale))
         H = int(base_resolution)
+        # grid.py:42-45: "manually handle autocast (only use half precision embeddings, inputs must be float for enough
+        # precision); if C % 2 != 0, force float, since half for atomicAdd is very slow"
+        if torch.is_autocast_enabled('cuda') and Cc % 2 == 0:
+            embeddings = embeddings.to(torch.half)
         outputs = torch.empty(L, B, Cc, device=inputs.device, dtype=embeddings.dtype)
         dy_dx = torch.empty(B, L * D * Cc, device=inputs.device, dtype=embeddings.dtype) \
             if calc_grad_inputs else None
@@ -70,6 +76,7 @@ class _GridEncode(Function):
         return outputs.permute(1, 0, 2).reshape(B, L * Cc)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, grad):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, Cc, L, S, H, gridtype, interpolation = ctx.dims

@@ -106,33 +106,51 @@ def _ptr_table(tensors, name):
 
 
 # ------------------------------------------------------------------ grid encoder (section 1)
-def _fp32_embeddings(embeddings, what):
-    """gridencoder.cu:467 dispatches on embeddings.scalar_type() over float / double / half (grid.py:42-45 feeds half
-    embeddings under autocast).  This build computes the encoder in fp32 only -- the dtype the rendering path uses and
-    the parity gate is stated in; other dtypes are refused by name instead of being silently converted."""
-    if torch.is_tensor(embeddings) and embeddings.dtype != torch.float32:
-        raise RuntimeError(f'{what}: embeddings are {embeddings.dtype}; this build implements the float32 dispatch case of '
-                           f'gridencoder.cu:467 only (float16 / float64 embeddings are not supported: cast with .float())')
+def _encoder_dtype(t, what):
+    """gridencoder.cu:467,500 dispatch on the tensor dtype over float / double / half (grid.py:42-45 feeds half embeddings
+    under autocast).  float32 and float16 are built; float64 -- which nothing on this path produces -- is refused by name
+    instead of being silently converted."""
+    if t.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f'{what}: tensors are {t.dtype}; this build implements the float32 and float16 dispatch cases of '
+                           f'gridencoder.cu:467 (float64 embeddings are not supported: cast with .float())')
+    return t.dtype
 
 
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H, dy_dx=None,
                         gridtype=0, align_corners=False, interp=0):
     """Same positional signature as the reference's `_gridencoder.grid_encode_forward`
-    (bindings.cpp:6); writes `outputs[L,B,C]` (and `dy_dx`) in place."""
-    _fp32_embeddings(embeddings, 'grid_encode_forward')
+    (bindings.cpp:6); writes `outputs[L,B,C]` (and `dy_dx`) in place.  Dispatches on embeddings.dtype like the reference."""
+    dt = _encoder_dtype(embeddings, 'grid_encode_forward')
     with _guard(inputs):
-        rc = _lib.lib().occnerf_grid_encode_forward_h(
-            _chk(inputs, torch.float32, 'inputs'), _chk(embeddings, torch.float32, 'embeddings'),
-            _chk(offsets, torch.int32, 'offsets'), _host_offsets(offsets), _chk(outputs, torch.float32, 'outputs'),
-            int(B), int(D), int(Cc), int(L), float(S), int(H), _opt(dy_dx, torch.float32, 'dy_dx'),
-            int(gridtype), int(bool(align_corners)), int(interp), _stream(inputs))
+        if dt == torch.float16:
+            rc = _lib.lib().occnerf_grid_encode_forward_f16(
+                _chk(inputs, torch.float32, 'inputs'), _chk(embeddings, torch.float16, 'embeddings'),
+                _chk(offsets, torch.int32, 'offsets'), _chk(outputs, torch.float16, 'outputs'),
+                int(B), int(D), int(Cc), int(L), float(S), int(H), _opt(dy_dx, torch.float16, 'dy_dx'),
+                int(gridtype), int(bool(align_corners)), int(interp), _stream(inputs))
+        else:
+            rc = _lib.lib().occnerf_grid_encode_forward_h(
+                _chk(inputs, torch.float32, 'inputs'), _chk(embeddings, torch.float32, 'embeddings'),
+                _chk(offsets, torch.int32, 'offsets'), _host_offsets(offsets), _chk(outputs, torch.float32, 'outputs'),
+                int(B), int(D), int(Cc), int(L), float(S), int(H), _opt(dy_dx, torch.float32, 'dy_dx'),
+                int(gridtype), int(bool(align_corners)), int(interp), _stream(inputs))
     _lib.check(rc, 'grid_encode_forward')
 
 
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H,
                          dy_dx=None, grad_inputs=None, gridtype=0, align_corners=False, interp=0):
-    """`_gridencoder.grid_encode_backward` (bindings.cpp:7)."""
-    _fp32_embeddings(embeddings, 'grid_encode_backward')
+    """`_gridencoder.grid_encode_backward` (bindings.cpp:7); dispatches on grad.dtype like the reference (:500)."""
+    dt = _encoder_dtype(grad, 'grid_encode_backward')
+    if dt == torch.float16:
+        with _guard(inputs):
+            rc = _lib.lib().occnerf_grid_encode_backward_f16(
+                _chk(grad, torch.float16, 'grad'), _chk(inputs, torch.float32, 'inputs'),
+                _chk(embeddings, torch.float16, 'embeddings'), _chk(offsets, torch.int32, 'offsets'),
+                _chk(grad_embeddings, torch.float16, 'grad_embeddings'), int(B), int(D), int(Cc), int(L), float(S), int(H),
+                _opt(dy_dx, torch.float16, 'dy_dx'), _opt(grad_inputs, torch.float16, 'grad_inputs'), int(gridtype),
+                int(bool(align_corners)), int(interp), _stream(inputs))
+        _lib.check(rc, 'grid_encode_backward')
+        return
     # room for the tile-set pre-pass of the tiled backward (large D = 4, C = 2 batches only)
     scratch = torch.empty(int(L) * int(B), device=inputs.device, dtype=torch.int64) if (int(D) == 4 and int(Cc) == 2
                                                                                       and int(B) >= 32768) else None

@@ -216,6 +216,188 @@ OC_EXPORT void oc_grid_encode_backward(const float *grad, const float *inputs,
 }
 
 /* ------------------------------------------------------------------------- */
+/* a14/a19 with scalar_t = at::Half (gridencoder.cu:467,500: the dispatch case grid.py:44-45 selects under
+ * autocast).  c10::Half arithmetic (c10/util/Half-inl.h): every operator converts to float, computes, and
+ * rounds the result to half (round-to-nearest-even); `Half += float` converts the float operand to Half first.
+ * Half storage is uint16_t here; the two conversions are spelled out in integer arithmetic.               */
+/* ------------------------------------------------------------------------- */
+static inline float oc_h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) { bits = sign; }
+        else {                                                 /* subnormal half: value = man * 2^-24 */
+            float v = (float)man * 5.9604644775390625e-08f;
+            memcpy(&bits, &v, 4);
+            bits |= sign;
+        }
+    } else if (exp == 31) { bits = sign | 0x7f800000u | (man << 13); }
+    else { bits = sign | ((exp + 112u) << 23) | (man << 13); }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static inline uint16_t oc_f2h(float f) {                      /* round to nearest even, like __float2half_rn */
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);              /* >= 65520 rounds to infinity */
+    if (x < 0x33000001u) return sign;                                      /* <= 2^-25 rounds to zero */
+    if (x < 0x38800000u) {                                                 /* subnormal half */
+        const int e = (int)(x >> 23);                                      /* biased float exponent, 102..112 */
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;                                         /* 14..24 */
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((x >> 23) - 112u) << 10 | ((x >> 13) & 0x3ffu);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+    return (uint16_t)(sign | r);
+}
+
+OC_EXPORT void oc_half_to_float(const uint16_t *h, float *f, int64_t n) { for (int64_t i = 0; i < n; i++) f[i] = oc_h2f(h[i]); }
+OC_EXPORT void oc_float_to_half(const float *f, uint16_t *h, int64_t n) { for (int64_t i = 0; i < n; i++) h[i] = oc_f2h(f[i]); }
+
+static inline uint16_t oc_hadd(uint16_t a, uint16_t b) { return oc_f2h(oc_h2f(a) + oc_h2f(b)); }
+
+/* gridencoder.cu:87-245 with scalar_t = at::Half: embeddings, outputs[L,B,C], dy_dx[B,L,D,C] half; inputs float. */
+OC_EXPORT void oc_grid_encode_forward_f16(const float *inputs, const uint16_t *embeddings, const int32_t *offsets,
+                                          uint16_t *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                          uint32_t H, uint16_t *dy_dx, uint32_t gridtype, int align_corners,
+                                          uint32_t interp) {
+    float scale_l[32];
+    uint32_t res_l[32];
+    oc_grid_level_params(L, S, H, scale_l, res_l);
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        const float *x = inputs + (size_t)b * D;
+        int oob = 0;
+        for (uint32_t d = 0; d < D; d++)
+            if (x[d] < 0 || x[d] > 1) oob = 1;
+        for (uint32_t level = 0; level < L; level++) {
+            uint16_t *out = outputs + ((size_t)level * B + b) * C;
+            uint16_t *dyl = dy_dx ? dy_dx + ((size_t)b * L + level) * D * C : NULL;
+            if (oob) {
+                for (uint32_t ch = 0; ch < C; ch++) out[ch] = 0;
+                if (dyl) for (uint32_t i = 0; i < D * C; i++) dyl[i] = 0;
+                continue;
+            }
+            const uint16_t *grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+            const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+            const float scale = scale_l[level];
+            float pos[8], pos_deriv[8];
+            uint32_t pos_grid[8];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) {
+                    pos_deriv[d] = 6 * pos[d] * (1.0f - pos[d]);
+                    pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+                } else {
+                    pos_deriv[d] = 1.0f;
+                }
+            }
+            uint16_t results[8] = {0};
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+                uint32_t pl[8];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = oc_grid_index(D, C, gridtype, align_corners, hashmap_size, res_l[level], pl);
+                for (uint32_t ch = 0; ch < C; ch++)            /* results[ch] += w * grid[index + ch];   :189 */
+                    results[ch] = oc_hadd(results[ch], oc_f2h(w * oc_h2f(grid[index + ch])));
+            }
+            for (uint32_t ch = 0; ch < C; ch++) out[ch] = results[ch];
+            if (dyl) {
+                for (uint32_t gd = 0; gd < D; gd++) {
+                    uint16_t rg[8] = {0};
+                    for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                        float w = scale;
+                        uint32_t pl[8];
+                        for (uint32_t nd = 0; nd < D - 1; nd++) {
+                            const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                            if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                            else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+                        }
+                        pl[gd] = pos_grid[gd];
+                        const uint32_t il = oc_grid_index(D, C, gridtype, align_corners, hashmap_size, res_l[level], pl);
+                        pl[gd] = pos_grid[gd] + 1;
+                        const uint32_t ir = oc_grid_index(D, C, gridtype, align_corners, hashmap_size, res_l[level], pl);
+                        for (uint32_t ch = 0; ch < C; ch++) {  /* += w * (grid[r] - grid[l]) * pos_deriv[gd];   :234 */
+                            const uint16_t diff = oc_f2h(oc_h2f(grid[ir + ch]) - oc_h2f(grid[il + ch]));
+                            rg[ch] = oc_hadd(rg[ch], oc_f2h((w * oc_h2f(diff)) * pos_deriv[gd]));
+                        }
+                    }
+                    for (uint32_t ch = 0; ch < C; ch++) dyl[gd * C + ch] = rg[ch];
+                }
+            }
+        }
+    }
+}
+
+/* gridencoder.cu:248-369 with scalar_t = at::Half (C even: half2 atomics, each lane one half add).  The device order of
+ * the atomics is free; here (level, b, corner) order -- comparisons carry a half-rounding tolerance. */
+OC_EXPORT void oc_grid_encode_backward_f16(const uint16_t *grad, const float *inputs, const int32_t *offsets,
+                                           uint16_t *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                           float S, uint32_t H, const uint16_t *dy_dx, uint16_t *grad_inputs,
+                                           uint32_t gridtype, int align_corners, uint32_t interp) {
+    float scale_l[32];
+    uint32_t res_l[32];
+    oc_grid_level_params(L, S, H, scale_l, res_l);
+    for (uint32_t level = 0; level < L; level++) {
+        uint16_t *gg = grad_embeddings + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *x = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[8];
+            uint32_t pos_grid[8];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(x[d], scale_l[level], align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+            }
+            const uint16_t *g = grad + ((size_t)level * B + b) * C;
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+                uint32_t pl[8];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = oc_grid_index(D, C, gridtype, align_corners, hashmap_size, res_l[level], pl);
+                for (uint32_t ch = 0; ch < C; ch++)
+                    gg[index + ch] = oc_hadd(gg[index + ch], oc_f2h(w * oc_h2f(g[ch])));
+            }
+        }
+    }
+    if (dy_dx && grad_inputs) {
+        for (uint32_t b = 0; b < B; b++)
+            for (uint32_t d = 0; d < D; d++) {
+                uint16_t r = 0;
+                for (uint32_t l = 0; l < L; l++)
+                    for (uint32_t ch = 0; ch < C; ch++)       /* result += grad[..] * dy_dx[..];   :362 */
+                        r = oc_hadd(r, oc_f2h(oc_h2f(grad[((size_t)l * B + b) * C + ch]) *
+                                              oc_h2f(dy_dx[(((size_t)b * L + l) * D + d) * C + ch])));
+                grad_inputs[(size_t)b * D + d] = r;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* a6: samples along rays.  network.py:405-432,456                            */
 /* rays[n,8] = (o, d, near, far); t_vals[S] = torch.linspace(0,1,S) (passed   */
 /* in so its rounding is torch's own); t_rand[n,S] or NULL (perturb == 0).    */

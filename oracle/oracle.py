@@ -99,6 +99,53 @@ def grid_encode_backward(grad, inputs, offsets, n_emb, Cc, S, H, dy_dx=None, gri
     return ge, gi
 
 
+_u16p = C.POINTER(C.c_uint16)
+
+
+def _f16(a):
+    return np.ascontiguousarray(a, dtype=np.float16)
+
+
+def grid_encode_forward_f16(inputs, embeddings, offsets, S, H, want_dy_dx=False, gridtype=0, align_corners=False, interp=0):
+    """gridencoder.cu:467's at::Half dispatch case: float16 embeddings -> float16 outputs[L,B,C] (, dy_dx[B,L*D*C])."""
+    inputs, embeddings, offsets = _f32(inputs), _f16(embeddings), _i32(offsets)
+    B, D = inputs.shape
+    Cc = embeddings.shape[1]
+    L = offsets.shape[0] - 1
+    out = np.empty((L, B, Cc), np.float16)
+    dy = np.empty((B, L * D * Cc), np.float16) if want_dy_dx else None
+    lib().oc_grid_encode_forward_f16(_p(inputs, _f32p), _p(embeddings, _u16p), _p(offsets, _i32p), _p(out, _u16p),
+                                     C.c_uint32(B), C.c_uint32(D), C.c_uint32(Cc), C.c_uint32(L), C.c_float(S),
+                                     C.c_uint32(H), _p(dy, _u16p), C.c_uint32(gridtype), C.c_int(int(align_corners)),
+                                     C.c_uint32(interp))
+    return out, dy
+
+
+def grid_encode_backward_f16(grad, inputs, offsets, n_emb, Cc, S, H, dy_dx=None, gridtype=0, align_corners=False, interp=0):
+    """float16 grad[L,B,C] -> float16 grad_embeddings[n_emb,C] (sequential half accumulation), grad_inputs[B,D] or None."""
+    grad, inputs, offsets = _f16(grad), _f32(inputs), _i32(offsets)
+    B, D = inputs.shape
+    L = offsets.shape[0] - 1
+    ge = np.zeros((n_emb, Cc), np.float16)
+    gi = np.zeros((B, D), np.float16) if dy_dx is not None else None
+    dy = _f16(dy_dx) if dy_dx is not None else None
+    lib().oc_grid_encode_backward_f16(_p(grad, _u16p), _p(inputs, _f32p), _p(offsets, _i32p), _p(ge, _u16p), C.c_uint32(B),
+                                      C.c_uint32(D), C.c_uint32(Cc), C.c_uint32(L), C.c_float(S), C.c_uint32(H),
+                                      _p(dy, _u16p), _p(gi, _u16p), C.c_uint32(gridtype), C.c_int(int(align_corners)),
+                                      C.c_uint32(interp))
+    return ge, gi
+
+
+def half_roundtrip(values):
+    """float32 -> float16 -> float32 through the oracle's own conversions (checked against numpy's in the tests)."""
+    f = _f32(values).ravel()
+    h = np.empty(f.shape, np.uint16)
+    lib().oc_float_to_half(_p(f, _f32p), _p(h, _u16p), C.c_int64(f.size))
+    back = np.empty(f.shape, np.float32)
+    lib().oc_half_to_float(_p(h, _u16p), _p(back, _f32p), C.c_int64(f.size))
+    return h.view(np.float16), back
+
+
 def sample_rays(rays8, t_vals, t_rand=None):
     rays8, t_vals = _f32(rays8), _f32(t_vals)
     n, S = rays8.shape[0], t_vals.shape[0]

@@ -90,16 +90,91 @@ def test_ops_refuse_cpu_tensors(ops):
 
 
 def test_operator_seam_dtype_errors(ops):
-    """gridencoder.cu:467 dispatches float / double / half; this build implements float only and says so by name."""
+    """gridencoder.cu:467 dispatches float / double / half; this build implements float and half and refuses double by
+    name; mismatched tensors of a call are refused too."""
     x = torch.rand(8, 4, device=DEV)
     off = torch.tensor([0, 64], dtype=torch.int32, device=DEV)
-    for dt in (torch.float16, torch.float64):
-        with pytest.raises(RuntimeError, match=str(dt).replace('torch.', '')):
-            ops.grid_encode_forward(x, torch.zeros(64, 2, device=DEV, dtype=dt), off, torch.zeros(1, 8, 2, device=DEV), 8, 4,
-                                    2, 1, 1.0, 16)
-        with pytest.raises(RuntimeError, match=str(dt).replace('torch.', '')):
-            ops.grid_encode_backward(torch.zeros(1, 8, 2, device=DEV), x, torch.zeros(64, 2, device=DEV, dtype=dt), off,
-                                     torch.zeros(64, 2, device=DEV), 8, 4, 2, 1, 1.0, 16)
+    with pytest.raises(RuntimeError, match='float64'):
+        ops.grid_encode_forward(x, torch.zeros(64, 2, device=DEV, dtype=torch.float64), off, torch.zeros(1, 8, 2, device=DEV),
+                                8, 4, 2, 1, 1.0, 16)
+    with pytest.raises(RuntimeError, match='float64'):
+        ops.grid_encode_backward(torch.zeros(1, 8, 2, device=DEV, dtype=torch.float64), x, torch.zeros(64, 2, device=DEV), off,
+                                 torch.zeros(64, 2, device=DEV), 8, 4, 2, 1, 1.0, 16)
+    with pytest.raises(RuntimeError):                       # half embeddings need half outputs, as data_ptr<scalar_t>() insists
+        ops.grid_encode_forward(x, torch.zeros(64, 2, device=DEV, dtype=torch.float16), off, torch.zeros(1, 8, 2, device=DEV),
+                                8, 4, 2, 1, 1.0, 16)
+    with pytest.raises(RuntimeError, match='C = 1'):        # the reference's half atomicAdd for odd C is an empty stub
+        h = torch.float16
+        ops.grid_encode_backward(torch.zeros(1, 8, 1, device=DEV, dtype=h), x, torch.zeros(64, 1, device=DEV, dtype=h), off,
+                                 torch.zeros(64, 1, device=DEV, dtype=h), 8, 4, 1, 1, 1.0, 16)
+
+
+@pytest.mark.parametrize('D,Cc,gridtype,interp,align', [(4, 2, 0, 0, False), (3, 2, 0, 1, False), (3, 4, 1, 0, True),
+                                                       (2, 8, 0, 0, False), (5, 2, 0, 0, False), (4, 1, 0, 0, False)])
+def test_grid_encode_half_dispatch(ops, oracle, D, Cc, gridtype, interp, align):
+    """The at::Half dispatch case of the operator (gridencoder.cu:467,500; what grid.py:44-45 feeds under autocast) against
+    the oracle's restatement of c10::Half arithmetic: outputs and dy_dx bit for bit (the per-corner order is fixed),
+    also within one half-ulp of the fp32 evaluation rounded to half; the input gradient bit for bit; the embedding
+    gradient (packed-half atomics in free order) within half rounding of the sequential sum."""
+    from occnerf_amd.gridencoder import grid_offsets
+    rng = np.random.RandomState(100 + D * 10 + Cc)
+    L = 8
+    offsets, pls = grid_offsets(D, L, 1.6, 4, 12, align_corners=align)
+    emb = rng.uniform(-1, 1, (int(offsets[-1]), Cc)).astype(np.float16)
+    x = rng.uniform(0, 1, (1031, D)).astype(np.float32)
+    x[0], x[1], x[2], x[4] = 0.0, 1.0, -1e-6, 0.5
+    x[3, -1] = 1.0 + 1e-6
+    S, B = float(np.log2(pls)), x.shape[0]
+    out = torch.empty(L, B, Cc, device=DEV, dtype=torch.float16)
+    dy = torch.empty(B, L * D * Cc, device=DEV, dtype=torch.float16)
+    ops.grid_encode_forward(T(x), T(emb), T(offsets), out, B, D, Cc, L, S, 4, dy, gridtype, align, interp)
+    want, want_dy = oracle.grid_encode_forward_f16(x, emb, offsets, S, 4, True, gridtype, align, interp)
+    same(out.cpu().numpy().view(np.uint16), want.view(np.uint16), 'half outputs')
+    same(dy.cpu().numpy().view(np.uint16), want_dy.view(np.uint16), 'half dy_dx')
+    assert not out[:, 2].any() and not out[:, 3].any()
+    # against the fp32 operator on the same (half-valued) table: the 2^D half-rounded accumulation steps stay within
+    # a few half-ulps of the largest partial sum (|result| <= 1 here: ulp 2^-11 .. 2^-10)
+    f32, _ = oracle.grid_encode_forward(x, emb.astype(np.float32), offsets, S, 4, False, gridtype, align, interp)
+    assert np.abs(out.float().cpu().numpy() - f32).max() <= (1 << D) * 2.0 ** -11
+    if Cc == 1:
+        return                                               # no half backward for odd C (refused by name, tested above)
+    grad = (rng.randn(L, B, Cc) * 0.1).astype(np.float16)
+    ge = torch.zeros(emb.shape, device=DEV, dtype=torch.float16)
+    gi = torch.zeros(B, D, device=DEV, dtype=torch.float16)
+    ops.grid_encode_backward(T(grad), T(x), T(emb), T(offsets), ge, B, D, Cc, L, S, 4, dy, gi, gridtype, align, interp)
+    wge, wgi = oracle.grid_encode_backward_f16(grad, x, offsets, emb.shape[0], Cc, S, 4, want_dy, gridtype, align, interp)
+    same(gi.cpu().numpy().view(np.uint16), wgi.view(np.uint16), 'half grad_inputs')
+    got = ge.float().cpu().numpy()
+    ref32, _ = oracle.grid_encode_backward(grad.astype(np.float32), x, offsets, emb.shape[0], Cc, S, 4, None, gridtype,
+                                           align, interp)
+    # per cell n half-rounded additions: error <= n * half-ulp of the running sum; cells of the coarse levels collect
+    # hundreds of terms, so the bound is relative to the largest entry -- and the device is as close to the exact sum
+    # as the sequential restatement is
+    scale = np.abs(ref32).max()
+    assert np.abs(got - ref32).max() <= 0.02 * scale
+    assert np.abs(got - ref32).max() <= 2.0 * max(np.abs(wge.astype(np.float32) - ref32).max(), 2.0 ** -11 * scale)
+
+
+def test_grid_encoder_module_under_autocast(ops):
+    """grid.py:42-45: under autocast the module casts the embeddings to half (even C), the output is half, the input
+    stays float, and the gradient arrives at the fp32 parameter; without autocast everything stays fp32."""
+    from occnerf_amd.gridencoder import GridEncoder
+    torch.manual_seed(0)
+    enc = GridEncoder(input_dim=3, num_levels=4, level_dim=2, base_resolution=4, log2_hashmap_size=10).to(DEV)
+    enc.embeddings.data.uniform_(-1, 1)
+    x = torch.rand(257, 3, device=DEV)
+    with torch.autocast('cuda', dtype=torch.float16):
+        y = enc(x, bound=None)
+        assert y.dtype == torch.float16
+        y.float().square().sum().backward()
+    g16 = enc.embeddings.grad.clone()
+    assert g16.dtype == torch.float32 and bool(torch.isfinite(g16).all()) and float(g16.abs().max()) > 0
+    enc.embeddings.grad = None
+    y32 = enc(x, bound=None)
+    assert y32.dtype == torch.float32
+    y32.square().sum().backward()
+    assert float((y.float() - y32).detach().abs().max()) <= 8 * 2.0 ** -11 * max(1.0, float(y32.detach().abs().max()))
+    assert float((g16 - enc.embeddings.grad).abs().max()) <= 0.05 * float(enc.embeddings.grad.abs().max())
 
 
 def test_operator_forward_d4c2_equals_reference_shaped_kernel(ops):

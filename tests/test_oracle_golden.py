@@ -209,3 +209,26 @@ def test_make_golden_reproduces_committed_fixtures(tmp_path):
                 assert np.abs(a[k].astype(np.float64) - b[k]).max() <= 1e-5 * scale + 1e-9, (f, k)
             else:
                 assert np.array_equal(a[k], b[k]), (f, k)
+
+
+def test_oracle_half_conversions_match_ieee(oracle):
+    """The integer-arithmetic half <-> float conversions behind the oracle's at::Half restatement (gridencoder.cu:467's
+    half dispatch case): every half pattern to float, and float -> half round-to-nearest-even incl. ties, subnormals,
+    overflow, against numpy's IEEE binary16."""
+    import ctypes as C
+    allh = np.arange(65536, dtype=np.uint16)
+    f = np.empty(65536, np.float32)
+    oracle.lib().oc_half_to_float(allh.ctypes.data_as(C.POINTER(C.c_uint16)), f.ctypes.data_as(C.POINTER(C.c_float)),
+                                  C.c_int64(65536))
+    ref = allh.view(np.float16).astype(np.float32)
+    assert bool(((f.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(f) & np.isnan(ref))).all())
+    rng = np.random.RandomState(0)
+    with np.errstate(over='ignore', invalid='ignore'):
+        mids = ((ref[:-1].astype(np.float64) + ref[1:].astype(np.float64)) / 2)
+        mids = mids[np.isfinite(mids)].astype(np.float32)
+        v = np.concatenate([(rng.randn(200000) * 10 ** rng.uniform(-9, 5, 200000)).astype(np.float32), mids,
+                            np.array([0, -0.0, 65504, 65519.9, 65520, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 6.1e-5, np.inf,
+                                      -np.inf], np.float32)])
+        want = v.astype(np.float16)
+    h, _ = oracle.half_roundtrip(v)
+    assert np.array_equal(h.view(np.uint16), want.view(np.uint16))
