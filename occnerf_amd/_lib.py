@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liboccnerf_hip.so')
+# OCCNERF_HIP_LIB=<path>: load another build of the same library (A/B timing of kernel variants); never a different backend
+LIB_PATH = os.environ.get('OCCNERF_HIP_LIB') or os.path.join(_HERE, 'liboccnerf_hip.so')
 
 ABI_VERSION = 2          # include/occnerf_hip.h OCCNERF_ABI_VERSION this binding mirrors
 

@@ -1331,3 +1331,38 @@ def test_two_process_sharded_movement_at_size():
     assert got['world_size_formed'] == 2 and got['kind'] == 'movement' and got['size'] == 512 and got['spp'] == 128
     assert got['bit_identical'] and got['max_abs_diff'] == 0.0, got
     assert min(got['rays']) > 100000
+
+
+def test_feature_kernel_row_cache_variant_is_bit_identical(ops):
+    """The opt-in per-wave row cache of the feature kernel (OCCNERF_FEATURES_ROWCACHE=1: distinct table rows of a wave trip
+    staged in LDS by LDS-DMA, csrc/features.hip sample_features8r_kernel) against the shipped kernel on a 256x256 x 128 frame:
+    the 68-float MLP input rows and the signed distances bit for bit (it is slower, hence opt-in: profiles/r03_features_rowcache.md)."""
+    from occnerf_amd import synth
+    net, ctx = build_network(seed=0, amplify=True, S=128, non_rigid=True)
+    net.cfg.dedup_repeated_samples = False
+    frame = synth.make_frame(img_size=256, pose72=synth.seeded_pose(3), orbit_frame=11)
+    data = frame_to_device(frame, DEV)
+    grabbed = {}
+    real = ops.sample_features
+
+    def grab(*a, **k):
+        grabbed['a'], grabbed['k'] = a, dict(k)
+        return real(*a, **k)
+    ops.sample_features = grab
+    try:
+        with torch.no_grad():
+            net(**data, iter_val=1e7)
+    finally:
+        ops.sample_features = real
+    n = int(grabbed['k']['count'])
+    assert n > 96 * 64
+    outs = []
+    for mode in ('0', '1'):
+        os.environ['OCCNERF_FEATURES_ROWCACHE'] = mode
+        try:
+            o = real(*grabbed['a'], **grabbed['k'])
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop('OCCNERF_FEATURES_ROWCACHE', None)
+        outs.append((o[0][:n].clone(), o[1][:n, 4].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
