@@ -77,7 +77,7 @@ def cpu_baseline(ctx, frame, n_rays):
 def pmc_traffic(n_samples):
     """HBM bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 cannot run
     inside this process); only quoted when it was collected at the same launch size."""
-    for name in ('r02_pmc_hbm.json', 'r01_pmc_hbm.json'):
+    for name in ('r03_pmc_hbm.json', 'r02_pmc_hbm.json', 'r01_pmc_hbm.json'):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if abs(int(d['samples_per_launch']) - int(n_samples)) <= 1:

@@ -227,3 +227,4 @@ def test_ray_sharding_gather_gloo(n_rays, world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+

@@ -10,6 +10,8 @@
 //   mode 8  the TILES of csrc/nonrigid16.hip (46 chunks, two of them quarter-filled) with its MFMA-free phases added one at a time:
 //           bias/ReLU per layer, the output layer as VALU dots, inputs through the row list + the sincos embedding
 //   mode 9  mode 8 with the next tile's inputs and embedding moved inside the current tile's last layer
+//   mode 10 mode 9 with the two dependent loads issued layers ahead of their use
+//   mode 11 mode 10 with every request and first use placed right after a chunk's rendezvous (before that chunk's DMA issue)
 //   hipcc --offload-arch=gfx950 -O3 -o mir tools/mfma_issue_rate.hip && ./mir
 // Prints TFLOP/s and the fraction of the 157.3 TFLOP/s fp32-matrix peak (256 CUs x 4 SIMDs x 2.4 GHz x 512 FLOP / 8 cycles
 // per SIMD).
@@ -373,6 +375,39 @@ __global__ __launch_bounds__(kWaves * 64, 2) void k_nr_tiles(const float *__rest
                        "s"(ring_lds + (unsigned)(((c & (kSlots - 1)) * kChunk8 + frag * 64) * 16))
                      : "memory");
     };
+    int rq[2];
+    float xq[2][3];
+    auto request_rows = [&](int64_t n) {
+#pragma unroll
+        for (int T = 0; T < 2; T++) rq[T] = rows[(n + T * 16 + (lane & 15)) & 0xFFFFF];
+    };
+    auto request_xyz = [&]() {
+#pragma unroll
+        for (int T = 0; T < 2; T++)
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) xq[T][c2] = xyz[(int64_t)rq[T] * 3 + c2];
+    };
+    auto embed_from = [&](float (&ee)[2][12]) {
+#pragma unroll
+        for (int T = 0; T < 2; T++) {
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+                const int A = m < 4 ? m * 4 + g : 16 + (g >> 1);
+                const int oct = A / 3, c2 = A - 3 * oct;
+                const float a = (c2 == 0 ? xq[T][0] : c2 == 1 ? xq[T][1] : xq[T][2]) * (float)(1 << oct);
+                float sa, ca;
+                sincosf(a, &sa, &ca);
+                if (m < 4) {
+                    ee[T][2 * m] = sa;
+                    ee[T][2 * m + 1] = ca;
+                } else {
+                    ee[T][8] = (g & 1) ? ca : sa;
+                }
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) p[T][c2] = xq[T][c2];
+        }
+    };
     auto embed = [&](int64_t n, float (&ee)[2][12]) {          // inputs of one tile pair + their embedding
 #pragma unroll
         for (int T = 0; T < 2; T++) {
@@ -406,6 +441,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void k_nr_tiles(const float *__rest
     for (int i = 0; i < 4; i++) wA[i] = wB[i] = f32x4{1e-3f, 2e-3f, 1e-3f, 2e-3f};
     const f32x4 *slot = ring;
     if ((PH & 4) && (PH & 8)) embed((int64_t)(blockIdx.x * kWaves + wave) * 32, en);
+    rq[0] = rq[1] = 0;
+    xq[0][0] = xq[0][1] = xq[0][2] = xq[1][0] = xq[1][1] = xq[1][2] = 0.f;
 #pragma unroll 1
     for (int tile = 0; tile < tiles; tile++) {
         const int64_t n0 = ((int64_t)(tile * gridDim.x + blockIdx.x) * kWaves + wave) * 32;
@@ -420,7 +457,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void k_nr_tiles(const float *__rest
             }
         }
         // one chunk: CI = chunk index inside its layer (compile time), KS = k-steps of the layer, BOP(T, t) = B operand of k-step t
-#define NRT_CHUNK(CI, KS, BOP)                                                                                      \
+#define NRT_CHUNK_H(CI, KS, BOP, HOOK)                                                                                    \
         {                                                                                                           \
             _Pragma("unroll") for (int i = 0; i < 4; i++) wB[i] = slot[(4 + i) * 64 + lane];                        \
             _Pragma("unroll") for (int rr = 0; rr < 4; rr++) {                                                      \
@@ -434,6 +471,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void k_nr_tiles(const float *__rest
             __builtin_amdgcn_s_barrier();                                                                           \
             slot = ring + (c & (kSlots - 1)) * kChunk8;                                                             \
             c++;                                                                                                    \
+            HOOK                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < 4; i++) wA[i] = slot[i * 64 + lane];                              \
             _Pragma("unroll") for (int rr = 0; rr < 4; rr++) {                                                      \
                 if (rr < 2) issue1(c + 2, rr);                                                                      \
@@ -444,6 +482,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void k_nr_tiles(const float *__rest
                 }                                                                                                   \
             }                                                                                                       \
         }
+#define NRT_CHUNK(CI, KS, BOP) NRT_CHUNK_H(CI, KS, BOP, )
 #define NRT_LAYER_END(BOFF)                                                                                         \
         if (PH & 1) {                                                                                               \
             _Pragma("unroll") for (int T = 0; T < 2; T++)                                                           \
@@ -468,13 +507,24 @@ __global__ __launch_bounds__(kWaves * 64, 2) void k_nr_tiles(const float *__rest
                 NRT_CHUNK(8, 41, BOP_S) NRT_CHUNK(9, 41, BOP_S) NRT_CHUNK(10, 41, BOP_S)
                 NRT_LAYER_END(5)
             }
-            NRT_CHUNK(0, 32, BOP_A) NRT_CHUNK(1, 32, BOP_A) NRT_CHUNK(2, 32, BOP_A) NRT_CHUNK(3, 32, BOP_A)
-            if ((PH & 4) && (PH & 8) && l == 3)                  // next tile's inputs + embedding inside the last layer
+            // mode 10/11: the dependent loads are issued, and their results first touched, RIGHT AFTER a chunk's rendezvous --
+            // where the compiler's `s_waitcnt vmcnt(0)` for them finds the ring's DMAs landed (they were issued a chunk ago)
+            NRT_CHUNK_H(0, 32, BOP_A, if ((PH & 32) && l == 0) request_rows(n0 + (int64_t)gridDim.x * kWaves * 32);)
+            NRT_CHUNK(1, 32, BOP_A)
+            NRT_CHUNK_H(2, 32, BOP_A, if ((PH & 32) && l == 0) request_xyz();)
+            NRT_CHUNK_H(3, 32, BOP_A, if ((PH & 32) && l == 1) embed_from(en);)
+            if ((PH & 4) && (PH & 8) && !(PH & 48) && l == 3)    // next tile's inputs + embedding inside the last layer
                 embed(n0 + (int64_t)gridDim.x * kWaves * 32, en);
+            if (PH & 16) {                                       // ... requested two layers ahead of their use (mode 10)
+                if (l == 0) request_rows(n0 + (int64_t)gridDim.x * kWaves * 32);
+                if (l == 1) request_xyz();
+                if (l == 3) embed_from(en);
+            }
             NRT_CHUNK(4, 32, BOP_A) NRT_CHUNK(5, 32, BOP_A) NRT_CHUNK(6, 32, BOP_A) NRT_CHUNK(7, 32, BOP_A)
             NRT_LAYER_END(l + 1)
         }
 #undef NRT_CHUNK
+#undef NRT_CHUNK_H
 #undef NRT_LAYER_END
 #undef BOP_E
 #undef BOP_A
@@ -530,6 +580,78 @@ static void run_tiles(const float *pk, const int *rows, const float *xyz, float 
     const double tf = (double)blocks * kWaves * tiles * mfma_per_tile * 2.0 * 16 * 16 * 4 / (ms * 1e-3) / 1e12;
     printf("mode %d, 2 wave(s) per SIMD: %-58s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3  (block 0 ran at %.3f GHz)\n", mode, what, ms,
            tf, tf / 157.3, held_ghz());
+}
+
+
+// mode 12: mode 3 with HALF the rendezvous and DMA-issue count per MFMA: one workgroup of EIGHT waves per CU (still two waves
+// per SIMD) shares a 4-slot ring of 32 KiB chunks = 128 MFMAs per wave per barrier (32 ds_read_b128, 4 DMA fragments, 1
+// eight-wave barrier per 128 MFMAs).  The experiment VERDICT r02 item 9 asks for before touching csrc/mlp16.hip.
+__global__ __launch_bounds__(8 * 64, 1) void k_big_chunks(const float *__restrict__ pk, int groups, float *out) {
+    constexpr int kChunk32 = 2048, kW8 = 8;
+    __shared__ __attribute__((aligned(16))) f32x4 ring[kSlots * kChunk32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < kSlots * kChunk32; i += kW8 * 64) ring[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f};
+    __syncthreads();
+    CLK_BEGIN()
+    f32x4 acc[16], act[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        acc[i] = f32x4{0, 0, 0, 0};
+        act[i] = f32x4{lane * 1e-3f, 1.f, 2.f, 3.f};
+    }
+    const f32x4 *stream = reinterpret_cast<const f32x4 *>(pk);
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) f32x4 *)ring;
+    auto issue1 = [&](int c, int f) {
+        const int frag = wave * 4 + f;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane * 16), "s"(stream + (size_t)(c & 31) * kChunk32 + frag * 64),
+                       "s"(ring_lds + (unsigned)(((c & (kSlots - 1)) * kChunk32 + frag * 64) * 16))
+                     : "memory");
+    };
+    int c = 0;
+    for (int j = 0; j < 3; j++)
+        for (int f = 0; f < 4; f++) issue1(j, f);
+    f32x4 wA[8], wB[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) wA[i] = wB[i] = f32x4{1e-3f, 2e-3f, 1e-3f, 2e-3f};
+    const f32x4 *slot = ring;
+#pragma unroll 1
+    for (int gi = 0; gi < groups; gi++) {
+        // quarters 0..3 of the current slot: (ob 0-7, k 0-3), (ob 8-15, k 0-3), (ob 0-7, k 4-7), (ob 8-15, k 4-7)
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            f32x4 *cur = (qd & 1) ? wB : wA, *nxt = (qd & 1) ? wA : wB;
+            if (qd < 3) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) nxt[i] = slot[((qd + 1) * 8 + i) * 64 + lane];
+            } else {
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                slot = ring + (c & (kSlots - 1)) * kChunk32;
+                c++;
+#pragma unroll
+                for (int i = 0; i < 8; i++) nxt[i] = slot[i * 64 + lane];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                if (qd == 3) issue1(c + 2, rr);
+#pragma unroll
+                for (int ob = 0; ob < 8; ob++)
+                    acc[(qd & 1) * 8 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[ob][rr], act[(gi * 2 + (qd >> 1)) & 15][rr],
+                                                                                  acc[(qd & 1) * 8 + ob], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLK_END()
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + act[i][0];
+    if (s == 12345.678f) out[0] = s;
 }
 
 template <int MODE, int W>
@@ -615,6 +737,23 @@ int main() {
                "one tile, width 128: 8 ds_read, 2 DMA, 1 barrier per 32 MFMAs", ms, tf, tf / 157.3, held_ghz());
     }
     {
+        const int groups = 1024, blocks = 256 * 8;
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        float ms = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(k_big_chunks, dim3(blocks), dim3(8 * 64), 0, 0, pk, groups, out);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
+        }
+        const double tf = (double)blocks * 8 * groups * 128 * 2.0 * 16 * 16 * 4 / (ms * 1e-3) / 1e12;
+        printf("mode 12, 2 wave(s) per SIMD: %-57s %8.2f ms  %7.1f TFLOP/s  %.3f of 157.3  (block 0 ran at %.3f GHz)\n",
+               "mode 3 with 8-wave workgroups, 32 KiB chunks: 1 barrier, 4 DMA per 128 MFMAs", ms, tf, tf / 157.3, held_ghz());
+    }
+    {
         int *rows;
         float *xyz, *big;
         (void)hipMalloc(&rows, (1 << 20) * 4);
@@ -630,6 +769,8 @@ int main() {
         run_tiles<7>(pk, rows, xyz, big, "+ inputs through the row list + sincos embedding per tile", 8);
         run_tiles<15>(pk, rows, xyz, big, "same, next tile's inputs + embedding inside the last layer", 9);
         run_tiles<13>(pk, rows, xyz, big, "mode 9 without the output dots", 9);
+        run_tiles<31>(pk, rows, xyz, big, "row ids requested 3 layers, positions 2 layers before the embedding", 10);
+        run_tiles<47>(pk, rows, xyz, big, "same, every request / first use right after a chunk rendezvous", 11);
     }
     return 0;
 }

@@ -12,9 +12,9 @@ cat > /tmp/dd_frame.py <<'PY'
 import sys, torch
 sys.path.insert(0, '.')
 from occnerf_amd import synth
-from tests.gpu_util import build_network, frame_to_device
+from occnerf_amd.seeded import build_network, frame_to_device
 torch.set_grad_enabled(False)
-net, ctx = build_network(0, False, S=128, non_rigid=True)
+net = build_network(0, False, S=128, non_rigid=True)
 frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
 data = frame_to_device(frame, 'cuda:0')
 for _ in range(6):
@@ -25,4 +25,10 @@ PY
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_dedup -o d -- python3 /tmp/dd_frame.py > $o/prof_dedup.log 2>&1
 timeout -k 5 400 bash tools/pmc_mfma.sh $o/pmc_mfma.json > $o/pmc_mfma.log 2>&1
 timeout -k 5 300 bash tools/pmc_hbm.sh $o/pmc_hbm.json > $o/pmc_hbm.log 2>&1
+# calibration of FETCH_SIZE for streams vs gathers (tools/fetch_calib.hip), and the MFMA issue-rate microbenchmark
+hipcc --offload-arch=gfx950 -O3 -o /tmp/fc tools/fetch_calib.hip 2>/dev/null
+for m in 0 1 2; do
+  timeout -k 5 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/fc$m -o p -- /tmp/fc $m > $o/fc$m.log 2>&1
+done
+hipcc --offload-arch=gfx950 -O3 -o /tmp/mir tools/mfma_issue_rate.hip 2>/dev/null && /tmp/mir > $o/mfma_issue_rate.txt 2>&1
 ls $o
