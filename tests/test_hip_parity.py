@@ -689,7 +689,7 @@ def test_training_step_against_reference(golden):
     same(net.point_counter.detach().cpu().numpy(), g['out.point_counter'], 'point_counter after the step')
     loss = (out['rgb'] ** 2).mean() + 0.5 * out['alpha'].mean() + 0.01 * out['depth'].mean() \
         + 0.1 * out['comp_loss'].mean()
-    assert abs(float(loss) - float(g['out.loss'])) <= 1e-4
+    assert abs(float(loss.detach()) - float(g['out.loss'])) <= 1e-4
     loss.backward()
     grads = {n: p.grad for n, p in net.named_parameters()}
     assert sorted(n for n, v in grads.items() if v is None) == sorted(str(x) for x in g['grad.none'])
