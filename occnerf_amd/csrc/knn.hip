@@ -225,8 +225,14 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
         if (tile >= n_tiles) break;
         // lane = one of 64 neighbouring rays (the host orders rays in compact pixel patches),
         // its 4 queries = 4 consecutive samples of that ray
-        const int64_t ray = (tile / tiles_per_chunk) * 64 + lane;
-        const int s0 = (int)(tile % tiles_per_chunk) * 4;
+        // Ticket -> tile.  With a query list the tickets walk the sample chunks OUTERMOST (chunk j of every ray block, then
+        // chunk j + 1): the first chunks are full tiles -- every ray has a few listed samples -- and the last ones hold only
+        // the longest rays' remainders, so the heavy tiles are drawn first and the kernel's tail is made of light ones
+        // (a rank's eighth of a frame has < 4 tiles per resident wave).
+        const int64_t n_blocks = (n_rays + 63) / 64;
+        const int64_t blk = qrows ? tile % n_blocks : tile / tiles_per_chunk;
+        const int64_t ray = blk * 64 + lane;
+        const int s0 = (int)(qrows ? tile / n_blocks : tile % tiles_per_chunk) * 4;
         int64_t qi[kQ];
         bool live[kQ];
         f32x2 qx[2], qy[2], qz[2];
