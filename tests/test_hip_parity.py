@@ -1366,3 +1366,17 @@ def test_feature_kernel_row_cache_variant_is_bit_identical(ops):
             os.environ.pop('OCCNERF_FEATURES_ROWCACHE', None)
         outs.append((o[0][:n].clone(), o[1][:n, 4].clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_eight_process_sharded_render_one_gpu():
+    """The node size the path is built for: EIGHT ranks (sharing this one GPU, gloo through the host) render three frames with the
+    cost-aware shard plan, bit-identical to one rank; `bench.py --gpus 8` runs end to end and its per-rank live-sample counts are
+    within 1 % of their mean (the balance the plan exists for)."""
+    env = {'OCC_DIST_BACKEND': 'gloo', 'OCC_FORCE_DEVICE': '0'}
+    got = _torchrun(['tools/sharded_check.py'], 8, extra_env=env)
+    assert got['world_size_formed'] == 8 and got['bit_identical'] and got['max_abs_diff'] == 0.0, got
+    line = _torchrun(['bench.py', '--gpus', '8', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-alt'], 8, extra_env=env)
+    assert line['n_gpus'] == 8 and line['config']['world_size_formed'] == 8 and line['scaling'] == 'strong'
+    rays, live = line['config']['per_rank_rays'], line['config']['per_rank_live_samples']
+    assert sum(rays) == line['config']['rays_per_frame'] and len(live) == 8
+    assert max(rays) / (sum(rays) / 8) <= 1.01 and max(live) / (sum(live) / 8) <= 1.01, (rays, live)
