@@ -7,7 +7,6 @@ exp_decay.update_lr edits work), `state_dict()` with the same per-parameter keys
 `zero_grad` -- and evaluates clip + Adam with three launches of csrc/optim.hip (norm partials, norm, update)
 instead of ~25 foreach kernels; the gradient norm never visits the host.
 """
-import ctypes as C
 import math
 
 import numpy as np
