@@ -11,6 +11,8 @@
 //           bias/ReLU per layer, the output layer as VALU dots, inputs through the row list + the sincos embedding
 //   mode 9  mode 8 with the next tile's inputs and embedding moved inside the current tile's last layer
 //   mode 10 mode 9 with the two dependent loads issued layers ahead of their use
+//   mode 13 (MIR_MODE13=1) mode 3 with the DMA fragments issued as `buffer_load_dwordx4 off, V#, soffset lds` through a
+//           descriptor with ADD_TID_ENABLE: no address VGPR
 //   mode 11 mode 10 with every request and first use placed right after a chunk's rendezvous (before that chunk's DMA issue)
 //   hipcc --offload-arch=gfx950 -O3 -o mir tools/mfma_issue_rate.hip && ./mir
 // Prints TFLOP/s and the fraction of the 157.3 TFLOP/s fp32-matrix peak (256 CUs x 4 SIMDs x 2.4 GHz x 512 FLOP / 8 cycles
@@ -59,10 +61,26 @@ __global__ __launch_bounds__(kWaves * 64, WAVES_PER_SIMD) void k(const float *__
                        "s"(ring_lds + (unsigned)(((c & (kSlots - 1)) * kChunkF4 + frag * 64) * 16))
                      : "memory");
     };
+    // mode 13: the same fragments by `buffer_load_dwordx4 off, V#, soffset lds` through a descriptor with ADD_TID_ENABLE
+    // (address = base + soffset + 16 x lane formed by the address unit: no address VGPR is read at all)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long sbase = (unsigned long long)(size_t)stream;
+    const u32x4 vdesc = {(unsigned)sbase, (unsigned)((sbase >> 32) & 0xFFFFu) | (16u << 16), 1u << 28, (1u << 23) | 0x7000u};
+    auto issue1b = [&](int c, int f) {
+        const int frag = wave * 4 + f;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 off, %1, %2 lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(vdesc), "s"((unsigned)(((c & 63) * kChunkF4 + frag * 64) * 16)),
+                       "s"(ring_lds + (unsigned)(((c & (kSlots - 1)) * kChunkF4 + frag * 64) * 16))
+                     : "memory");
+    };
+#define ISSUE1(C, F) do { if (MODE == 13) issue1b((C), (F)); else issue1((C), (F)); } while (0)
     int c = 0;
     if (MODE >= 3) {
         for (int j = 0; j < 3; j++)
-            for (int f = 0; f < 4; f++) issue1(j, f);
+            for (int f = 0; f < 4; f++) ISSUE1(j, f);
     }
     f32x4 wA[8], wB[8];
 #pragma unroll
@@ -90,12 +108,12 @@ __global__ __launch_bounds__(kWaves * 64, WAVES_PER_SIMD) void k(const float *__
         }
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-            if (MODE >= 3) issue1(c + 2, rr);
+            if (MODE >= 3) ISSUE1(c + 2, rr);
 #pragma unroll
             for (int ob = 0; ob < 8; ob++)
                 acc[8 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[ob][rr], act[gi & 15][rr], acc[8 + ob], 0, 0, 0);
         }
-        if (MODE >= 4 && (gi & 15) == 15) {
+        if (MODE >= 4 && MODE < 13 && (gi & 15) == 15) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
 #pragma unroll
@@ -685,6 +703,7 @@ int main() {
     run<3, 2>(pk, out, "+ 4 LDS-DMA fragments per wave per 64 MFMAs, vmcnt(8)");
     run<4, 2>(pk, out, "+ bias/ReLU epilogue (128 VALU) every 16 groups");
     run<3, 1>(pk, out, "mode 3 with one wave per SIMD");
+    if (getenv("MIR_MODE13")) run<13, 2>(pk, out, "mode 3, DMA by buffer_load ... lds with ADD_TID (no address VGPR)");
     {
         const int groups = 2048, blocks = 256 * 2 * 8;
         hipEvent_t e0, e1;
