@@ -29,8 +29,9 @@ extern "C" {
 #endif
 
 /* Bumped whenever an existing export's signature or a table layout changes (2: composite/msknn_clustered/
- * sample_features grew arguments in round 2, the Adam table row carries per-tensor bias corrections). */
-#define OCCNERF_ABI_VERSION 2
+ * sample_features grew arguments in round 2, the Adam table row carries per-tensor bias corrections; 3: msknn_clustered
+ * takes the cluster groups). */
+#define OCCNERF_ABI_VERSION 3
 
 int occnerf_abi_version(void);
 const char *occnerf_last_error(void);
@@ -198,7 +199,10 @@ int occnerf_msknn(const float *xyz, int64_t N, const float *points, const int32_
  * original row within the scale << 16 | base-point index: the row is the tie-break key among equal
  * distances, the base index (< 65536) is what knn_idxs reports; centers[ncl,4];
  * cluster_ranges[nscale-1,ncl,2] row ranges into points; cluster_radius[nscale-1,ncl] >=
- * max |p - center| per cluster.  mask (nullable) [n_rays * samples_per_ray]: samples whose mask is
+ * max |p - center| per cluster.  group_centers[ngrp,4], group_ranges[ngrp,2], group_radius[nscale-1,ngrp] (nullable together,
+ * ngrp = 0): the clusters are listed group by group -- group g = clusters group_ranges[g][0..1) -- and group_radius bounds
+ * everything those clusters hold at a scale around group_centers[g] (< 0: nothing there), so a search tests the group spheres
+ * first and only the clusters of the groups in reach; same results.  mask (nullable) [n_rays * samples_per_ray]: samples whose mask is
  * exactly 0 (motion-weight sum, network.py:330: their alpha is multiplied by it) are skipped and their
  * knn_idxs rows left unwritten.  query_rows / n_query_dev / ray_start (nullable, together, instead of mask): the ascending
  * list of the samples to query (occnerf_live_rows or the heads of occnerf_repeat_heads) with its length in device memory and
@@ -207,6 +211,7 @@ int occnerf_msknn(const float *xyz, int64_t N, const float *points, const int32_
 int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t n_rays, int32_t samples_per_ray,
                             const float *points, const float *centers,
                             const int32_t *cluster_ranges, const float *cluster_radius, int32_t ncl,
+                            const float *group_centers, const int32_t *group_ranges, const float *group_radius, int32_t ngrp,
                             const int32_t *h_coarse_rows, const int32_t *h_seed_from_coarser,
                             int32_t nscale, const int32_t *query_rows, const int32_t *n_query_dev, int32_t *ray_start,
                             int32_t *knn_idxs, void *stream);

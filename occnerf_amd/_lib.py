@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCCNERF_HIP_LIB=<path>: load another build of the same library (A/B timing of kernel variants); never a different backend
 LIB_PATH = os.environ.get('OCCNERF_HIP_LIB') or os.path.join(_HERE, 'liboccnerf_hip.so')
 
-ABI_VERSION = 2          # include/occnerf_hip.h OCCNERF_ABI_VERSION this binding mirrors
+ABI_VERSION = 3          # include/occnerf_hip.h OCCNERF_ABI_VERSION this binding mirrors
 
 _vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
@@ -42,8 +42,8 @@ SIGNATURES = {
     'occnerf_nonrigid_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_nonrigid_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_msknn': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
-    'occnerf_msknn_clustered': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp,
-                                           _vp, _vp]),
+    'occnerf_msknn_clustered': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
+                                           _vp, _vp, _vp, _vp, _vp]),
     'occnerf_knn_small': (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'occnerf_unit_normals': (C.c_int, [_vp, _i32, _vp, _vp]),
     'occnerf_point_sdf': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

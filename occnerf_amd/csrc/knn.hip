@@ -200,7 +200,7 @@ __device__ __forceinline__ void consider_lex(KBest64 &b, float &thr, float &sb, 
 }
 
 struct ClusteredScales {
-    int nscale, ncl;
+    int nscale, ncl, ngrp;
     int coarse_begin, coarse_end;   // rows of the coarsest scale (original order, padded to 4)
     int seed[4];
 };
@@ -209,6 +209,8 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     const float *__restrict__ xyz, const float *__restrict__ mask /*nullable*/, int64_t n_rays, int S,
     const float4 *__restrict__ points, const float4 *__restrict__ centers,
     const int2 *__restrict__ ranges /*[nscale-1][ncl]*/, const float *__restrict__ radius /*[nscale-1][ncl]*/,
+    const float4 *__restrict__ gcenters /*[ngrp]*/, const int2 *__restrict__ granges /*[ngrp]: cluster index range*/,
+    const float *__restrict__ gradius /*[nscale-1][ngrp], < 0: empty*/,
     ClusteredScales sc, int32_t *__restrict__ knn_idxs, unsigned *__restrict__ ticket,
     const int32_t *__restrict__ qrows /*nullable: ascending list of the samples to query*/,
     const int32_t *__restrict__ ray_start /*with qrows: [n_rays + 1] first list entry of every ray*/) {
@@ -365,12 +367,8 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
                 const int2 range = rg[k_first];
                 OCC_SCAN(range.x, range.y)
             }
-            for (int k = 0; k < sc.ncl; k++) {
-                if (k == k_first) continue;
-                const int2 range = rg[k];
-                if (range.x >= range.y) continue;
-                const float4 c = centers[k];
-                const float r = rd[k];
+            // sphere test shared by groups and clusters: reject only if surely |q - c| - r > sb for every live query of the wave
+            auto in_reach = [&](const float4 c, const float r) -> bool {
                 bool want = false;
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
@@ -378,13 +376,33 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
                     const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
-                        // reject only if surely |q-c| - r > sb  (1e-5 relative slack >> fp32 error)
+                        // (1e-5 relative slack >> fp32 error)
                         const float lim = (sb[2 * h + e] + r) * 1.00001f;
                         want |= live[2 * h + e] && !(d2[e] > lim * lim);
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(want) == 0) continue;   // wave-uniform skip
-                OCC_SCAN(range.x, range.y)
+                return __builtin_amdgcn_ballot_w64(want) != 0;           // wave-uniform
+            };
+            // Clusters are listed group by group (geometry.build_knn_clusters): a group's sphere bounds everything its ~8
+            // clusters hold at this scale, so a tile tests the ~14 group spheres and only the clusters of the groups in reach
+            // instead of all 108 cluster spheres (those tests were a fifth of the kernel's instructions).
+            const int ngrp = sc.ngrp > 0 ? sc.ngrp : 1;
+            for (int gi = 0; gi < ngrp; gi++) {
+                int k_lo = 0, k_hi = sc.ncl;
+                if (sc.ngrp > 0) {
+                    const float gr = gradius[(size_t)l * sc.ngrp + gi];
+                    if (gr < 0.0f) continue;
+                    if (!in_reach(gcenters[gi], gr)) continue;
+                    const int2 gk = granges[gi];
+                    k_lo = gk.x, k_hi = gk.y;
+                }
+                for (int k = k_lo; k < k_hi; k++) {
+                    if (k == k_first) continue;
+                    const int2 range = rg[k];
+                    if (range.x >= range.y) continue;
+                    if (!in_reach(centers[k], rd[k])) continue;
+                    OCC_SCAN(range.x, range.y)
+                }
             }
             OCC_EMIT(l)
         }
@@ -495,7 +513,8 @@ __global__ void ray_list_ranges_kernel(const int32_t *__restrict__ qrows, const 
 OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t n_rays, int32_t samples_per_ray,
                                     const float *points,
                                     const float *centers, const int32_t *cluster_ranges,
-                                    const float *cluster_radius, int32_t ncl,
+                                    const float *cluster_radius, int32_t ncl, const float *group_centers,
+                                    const int32_t *group_ranges, const float *group_radius, int32_t ngrp,
                                     const int32_t *h_coarse_rows,
                                     const int32_t *h_seed_from_coarser, int32_t nscale,
                                     const int32_t *query_rows, const int32_t *n_query_dev, int32_t *ray_start,
@@ -509,9 +528,13 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t
                 "msknn_clustered: null argument");
     OCC_REQUIRE(nscale >= 2 && nscale <= 4, "msknn_clustered: nscale=%d unsupported (2..4)", nscale);
     OCC_REQUIRE(ncl >= 1, "msknn_clustered: ncl=%d", ncl);
+    OCC_REQUIRE((ngrp == 0 && !group_centers && !group_ranges && !group_radius) ||
+                    (ngrp > 0 && group_centers && group_ranges && group_radius),
+                "msknn_clustered: group_centers, group_ranges, group_radius and ngrp come together");
     ClusteredScales sc;
     sc.nscale = nscale;
     sc.ncl = ncl;
+    sc.ngrp = ngrp;
     sc.coarse_begin = h_coarse_rows[0];
     sc.coarse_end = h_coarse_rows[1];
     OCC_REQUIRE(sc.coarse_begin % 4 == 0 && (sc.coarse_end - sc.coarse_begin) % 4 == 0 &&
@@ -542,7 +565,8 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t
     hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, mask,
                        n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points),
                        reinterpret_cast<const float4 *>(centers), reinterpret_cast<const int2 *>(cluster_ranges),
-                       cluster_radius, sc, knn_idxs, ticket, query_rows, ray_start);
+                       cluster_radius, reinterpret_cast<const float4 *>(group_centers),
+                       reinterpret_cast<const int2 *>(group_ranges), group_radius, sc, knn_idxs, ticket, query_rows, ray_start);
     return check_launch("msknn_clustered");
 }
 

@@ -25,7 +25,7 @@ def farthest_point_sampling(points, ratio):
     return sel
 
 
-def build_knn_clusters(point_base, scale_indices):
+def build_knn_clusters(point_base, scale_indices, clusters_per_group=8):
     """Cluster layout for occnerf_msknn_clustered (include/occnerf_hip.h).
 
     point_base[P,3] float32; scale_indices = [arange(P), fps0, fps1, fps2] (rows of each
@@ -35,8 +35,13 @@ def build_knn_clusters(point_base, scale_indices):
     with +inf points; float4.w carries (as int bits) ORIGINAL row within the scale << 16 | base-point
     index: the row breaks distance ties, the base index is what the search reports.
 
+    The clusters are listed group by group: a group = the clusters nearest to one of the first ceil(ncl / 8) coarsest points
+    (farthest-point order: well spread), with a bounding sphere per scale around everything its clusters hold, so that the
+    search tests ~14 group spheres and the clusters of the few groups in reach instead of all 108 cluster spheres per scale.
+
     Returns dict of numpy arrays: points[M,4] f32, centers[ncl,4] f32, ranges[nscale-1,ncl,2] i32,
-    radius[nscale-1,ncl] f32, coarse_rows (begin, end)."""
+    radius[nscale-1,ncl] f32, coarse_rows (begin, end), group_centers[G,4] f32, group_ranges[G,2] i32 (cluster index
+    range), group_radius[nscale-1,G] f32 (< 0: no points at that scale)."""
     base = np.ascontiguousarray(point_base, dtype=np.float32)
     sets = [np.asarray(s, dtype=np.int64) for s in scale_indices]
     nscale = len(sets)
@@ -77,5 +82,27 @@ def build_knn_clusters(point_base, scale_indices):
     coarse = emit(base[cidx], np.arange(ncl), cidx)
     centers = np.zeros((ncl, 4), np.float32)
     centers[:, :3] = base[cidx]
-    return {'points': np.concatenate(rows, 0), 'centers': centers, 'ranges': ranges, 'radius': radius,
-            'coarse_rows': np.array(coarse, np.int32), 'ncl': ncl}
+    # groups of clusters (the index arrays are permuted; the point rows stay where they are)
+    ngrp = max(1, -(-ncl // int(clusters_per_group)))
+    seeds = centers64[:ngrp]
+    dg = np.linalg.norm(centers64[:, None, :] - seeds[None, :, :], axis=-1)
+    group_of = dg.argmin(1)
+    perm = np.argsort(group_of, kind='stable')
+    ranges, radius, centers = ranges[:, perm], radius[:, perm], centers[perm]
+    gsorted = group_of[perm]
+    group_ranges = np.zeros((ngrp, 2), np.int32)
+    group_centers = np.zeros((ngrp, 4), np.float32)
+    group_radius = np.full((nscale - 1, ngrp), -1.0, np.float32)
+    for gi in range(ngrp):
+        members = np.nonzero(gsorted == gi)[0]
+        group_ranges[gi] = (members[0], members[-1] + 1) if len(members) else (0, 0)
+        group_centers[gi, :3] = seeds[gi]
+        c32 = group_centers[gi, :3].astype(np.float64)
+        for l in range(nscale - 1):
+            reach = [np.linalg.norm(centers[k, :3].astype(np.float64) - c32) + float(radius[l, k]) for k in members
+                     if ranges[l, k, 0] < ranges[l, k, 1]]
+            if reach:
+                group_radius[l, gi] = np.float32(max(reach) * (1 + 1e-6) + 1e-7)
+    return {'points': np.concatenate(rows, 0), 'centers': np.ascontiguousarray(centers), 'ranges': np.ascontiguousarray(ranges),
+            'radius': np.ascontiguousarray(radius), 'coarse_rows': np.array(coarse, np.int32), 'ncl': ncl,
+            'group_centers': group_centers, 'group_ranges': group_ranges, 'group_radius': group_radius, 'ngrp': ngrp}

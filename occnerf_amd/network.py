@@ -158,7 +158,7 @@ class Network(nn.Module):
         normals = self.point_norms.to(dev).double().contiguous()
         cl = geometry.build_knn_clusters(base.cpu().numpy(), [s.numpy() for s in sets])
         clusters = {k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if k in
-                        ('points', 'index_map', 'centers', 'ranges', 'radius') else v)
+                        ('points', 'index_map', 'centers', 'ranges', 'radius', 'group_centers', 'group_ranges', 'group_radius') else v)
                     for k, v in cl.items()}
         self._ctx = {
             'clusters': clusters,

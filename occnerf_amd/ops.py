@@ -407,7 +407,9 @@ def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser, mask=None, rows=None,
         rc = _lib.lib().occnerf_msknn_clustered(
             _chk(xyz, torch.float32, 'xyz'), _opt(mask, torch.float32, 'mask'), int(n_rays), int(S),
             _chk(cl['points'], torch.float32, 'points'), _chk(cl['centers'], torch.float32, 'centers'), _chk(cl['ranges'], torch.int32, 'cluster_ranges'),
-            _chk(cl['radius'], torch.float32, 'cluster_radius'), int(cl['ncl']), pc, ps, nscale,
+            _chk(cl['radius'], torch.float32, 'cluster_radius'), int(cl['ncl']),
+            _opt(cl.get('group_centers'), torch.float32, 'group_centers'), _opt(cl.get('group_ranges'), torch.int32, 'group_ranges'),
+            _opt(cl.get('group_radius'), torch.float32, 'group_radius'), int(cl.get('ngrp', 0)), pc, ps, nscale,
             _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'),
             None if ray_start is None else ray_start.data_ptr(), out.data_ptr(), _stream(xyz))
     _lib.check(rc, 'msknn_clustered')

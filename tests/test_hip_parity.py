@@ -74,7 +74,7 @@ def _dev_model(ctx, ops):
 
 def test_library_is_the_hip_build(ops):
     from occnerf_amd import _lib
-    assert _lib.lib().occnerf_abi_version() == 2
+    assert _lib.lib().occnerf_abi_version() == 3
     assert torch.cuda.is_available() and 'gfx950' in torch.cuda.get_device_properties(0).gcnArchName
 
 
@@ -340,7 +340,8 @@ def _clusters(ctx):
     from occnerf_amd import geometry
     sets = [np.arange(len(ctx['point_base']))] + [np.asarray(f) for f in ctx['fps']]
     cl = geometry.build_knn_clusters(ctx['point_base'], sets)
-    return {k: (T(v) if k in ('points', 'index_map', 'centers', 'ranges', 'radius') else v) for k, v in cl.items()}
+    return {k: (T(v) if k in ('points', 'index_map', 'centers', 'ranges', 'radius', 'group_centers', 'group_ranges', 'group_radius') else v)
+            for k, v in cl.items()}
 
 
 def test_msknn_clustered_bit_exact(case, ops):
@@ -1380,3 +1381,27 @@ def test_eight_process_sharded_render_one_gpu():
     rays, live = line['config']['per_rank_rays'], line['config']['per_rank_live_samples']
     assert sum(rays) == line['config']['rays_per_frame'] and len(live) == 8
     assert max(rays) / (sum(rays) / 8) <= 1.01 and max(live) / (sum(live) / 8) <= 1.01, (rays, live)
+
+
+def test_msknn_cluster_groups_change_nothing(ops):
+    """The two-level culling (group spheres first, then the clusters of the groups in reach) against the flat scan over every
+    cluster sphere, and across group sizes: index-for-index identical on scattered queries near and far from the body."""
+    from occnerf_amd import geometry
+    ctx = util.model_context(0, False)
+    sets = [np.arange(len(ctx['point_base']))] + [np.asarray(f) for f in ctx['fps']]
+    rng = np.random.RandomState(5)
+    n_rays, S = 96, 16
+    q = (ctx['point_base'][rng.randint(0, 6890, n_rays * S)] + rng.randn(n_rays * S, 3).astype(np.float32) *
+         rng.choice([0.002, 0.05, 0.6], (n_rays * S, 1)).astype(np.float32))
+    dev = ('points', 'index_map', 'centers', 'ranges', 'radius', 'group_centers', 'group_ranges', 'group_radius')
+    outs = []
+    for per_group in (8, 3, 27, None):
+        cl = geometry.build_knn_clusters(ctx['point_base'], sets, clusters_per_group=per_group or 8)
+        if per_group is None:                                   # flat: no groups handed over
+            for k in ('group_centers', 'group_ranges', 'group_radius'):
+                cl.pop(k)
+            cl['ngrp'] = 0
+        cl = {k: (T(v) if k in dev else v) for k, v in cl.items()}
+        outs.append(ops.msknn_clustered(T(q), n_rays, S, cl, [1, 1, 1, 0]).cpu().numpy())
+    for o in outs[1:]:
+        same(o, outs[0], 'cluster groups')
