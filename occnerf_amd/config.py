@@ -89,7 +89,9 @@ _DEFAULTS = {
     'freeview': {'frame_idx': 0}, 'tpose': {}, 'movement': {}, 'train': {},
     # build-specific keys
     'smpl_model': 'auto',            # 'auto' | 'synthetic' | directory holding the SMPL pickles
-    'max_samples_per_pass': 1 << 26,  # samples resident per pipeline pass (~470 B each)
+    # samples resident per pipeline pass (~470 B each): 2^28 keeps a whole 1024^2 x 192 frame (141 M samples, 63 GiB peak of the
+    # 288 GB) in ONE pass; larger frames run in several, bit-identically
+    'max_samples_per_pass': 1 << 28,
     # 'fp32': exact fp32 MFMA (default, the parity/benchmark path); 'bf16x3': split-bf16 MFMA,
     # ~3x faster MLP, raw logits within ~1e-5 of fp32
     'mlp_precision': 'fp32',

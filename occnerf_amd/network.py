@@ -439,7 +439,7 @@ class Network(nn.Module):
                 rays8 = ops.pack_rays(rays_f, f32(near).reshape(-1), f32(far).reshape(-1), order)
                 out = (torch.empty(R, 3, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev))
                 # all rays of the frame in as few passes as memory allows
-                rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 26)) // S)
+                rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 28)) // S)
                 for i in range(0, R, rays_per_pass):
                     n = min(rays_per_pass, R - i)
                     if order is not None:

@@ -1086,8 +1086,8 @@ def test_config1_real_size(oracle):
 
 
 def test_config4_full_frame(oracle):
-    """BASELINE configs[3] as written: one full 1024x1024 x 192-sample frame (734 K rays, 141 M samples, three passes of
-    the memory-bounded route), non-rigid on, seeded visibility counts (the occlusion-aware aggregation): finite,
+    """BASELINE configs[3] as written: one full 1024x1024 x 192-sample frame (734 K rays, 141 M samples; three passes of
+    the memory-bounded route == the default single pass, bit for bit), non-rigid on, seeded visibility counts (the occlusion-aware aggregation): finite,
     deterministic, a 4 096-ray slice rendered alone is bit-identical, 96 rays against the full CPU oracle."""
     from occnerf_amd import synth
     net, ctx = build_network(seed=0, amplify=False, S=192, non_rigid=True)
@@ -1098,10 +1098,18 @@ def test_config4_full_frame(oracle):
     frame = synth.make_frame(img_size=1024, pose72=synth.seeded_pose(1), orbit_frame=28)
     data = frame_to_device(frame, DEV)
     R = frame['rays'].shape[1]
-    rays_per_pass = int(net.cfg.get('max_samples_per_pass', 1 << 26)) // 192
-    assert -(-R // rays_per_pass) >= 3                                # the memory-bounded route really runs in 3 passes
+    net.cfg.max_samples_per_pass = 1 << 26                            # the memory-bounded route: 3 passes of <= 64 M samples
+    rays_per_pass = int(net.cfg.max_samples_per_pass) // 192
+    assert -(-R // rays_per_pass) >= 3
     with torch.no_grad():
         out = net(**data, iter_val=1e7)
+        net.cfg.max_samples_per_pass = 1 << 28                        # the default: the whole frame in one pass (63 GiB)
+        assert R * 192 <= net.cfg.max_samples_per_pass
+        one = net(**data, iter_val=1e7)
+        for k in ('rgb', 'alpha', 'depth'):
+            assert torch.equal(one[k], out[k]), k
+        del one
+        net.cfg.max_samples_per_pass = 1 << 26
         assert all(bool(torch.isfinite(out[k]).all()) for k in ('rgb', 'alpha', 'depth'))
         out2 = net(**data, iter_val=1e7)
         for k in ('rgb', 'alpha', 'depth'):
