@@ -8,12 +8,17 @@ nn.DataParallel over *samples* with its per-call weight broadcast (network.py:68
 
 **Which rays go where.**  The frame's rays are first walked along the renderer's 2-D Morton curve
 (`rayorder.ray_patch_order`, the order `Network` renders in anyway), and that walk is dealt to the ranks in blocks of
-256 consecutive rays (a ~16x16 pixel patch), block b to rank b % N.  Three things follow: (i) the shares differ by at
-most one block -- max/mean rays per rank <= 1.003 at N = 8 for the 183 784-ray benchmark frame (the 4 096-ray chunks
-of round 2: 1.07); (ii) a rank's share is hundreds of patches spread over the whole image, so the *cost* per rank
-(live samples: a quarter of the samples are dead, unevenly over the image) evens out statistically
-(tools/shard_balance.py prints it); (iii) a block is a multiple of the 64-ray kNN tile and stays a compact pixel
-patch, so a rank's kernels see the same locality as a single GPU's.
+256 consecutive rays (a ~16x16 pixel patch).  The shares differ by at most one block -- max/mean rays per rank <= 1.003 at
+N = 8 for the 183 784-ray benchmark frame (the 4 096-ray chunks of round 2: 1.07) -- and a block is a multiple of the 64-ray
+kNN tile and stays a compact pixel patch, so a rank's kernels see the same locality as a single GPU's.  WHICH blocks a rank
+gets is decided by cost (`_block_costs`): a quarter of the samples are dead, unevenly over the image, and the static deal
+(block b to rank b % N) left the live samples per rank 4.7 % apart at N = 8; the blocks are therefore sorted by the live
+samples on every 16th of their rays and dealt serpentine, which brings the ranks within 0.1 % of each other
+(tools/shard_balance.py).
+
+The plan is computed by every rank for itself and must come out identical on all of them: it is a pure function of the frame
+and the model (Morton keys, stable sorts, the deterministic sampler/warp kernel on identical devices) -- no collective distributes
+it; ranks on dissimilar GPUs should construct the renderer with `balance=False` (the static deal depends on the rays only).
 
 `ShardedRenderer` keeps what does not change from frame to frame -- the shard index lists and the un-permutation
 into the caller's ray order (per `ray_order_key`: a sequence shot by one camera names it, as `Network.forward`'s
