@@ -50,3 +50,36 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text, f
                 assert 'liboccnerf_oracle' not in text, f
+
+
+def test_product_and_benchmark_do_not_import_the_test_package():
+    """bench.py, smoke(), run.py, train.py, the package and the tools must run without `tests/`: the seeded model
+    and frame plumbing live in occnerf_amd/seeded.py, the oracle chain in oracle/chain.py.  (tools/debug_train.py is a debugging aid
+    for the tests themselves.)"""
+    import glob
+    files = ['bench.py', '__graft_entry__.py', 'run.py', 'train.py'] + glob.glob(os.path.join(ROOT, 'occnerf_amd', '*.py')) + \
+        [f for f in glob.glob(os.path.join(ROOT, 'tools', '*.py')) if not f.endswith('debug_train.py')] + \
+        glob.glob(os.path.join(ROOT, 'oracle', '*.py')) + glob.glob(os.path.join(ROOT, 'core', '**', '*.py'), recursive=True)
+    for f in files:
+        text = open(f if os.path.isabs(f) else os.path.join(ROOT, f)).read()
+        assert 'from tests' not in text and 'import tests' not in text, f
+
+
+def test_synthetic_frame_source_types():
+    """The frame source behind core/data/create_dataset.py: frame counts per type as the reference's datasets define them
+    (tpose 1, allview 23 = allview.py:69, progress <= 300 = create_dataset.py:40-42) and the per-frame dict's keys."""
+    from occnerf_amd.sequence import SyntheticFrames
+    assert len(SyntheticFrames('tpose', img_size=16)) == 1
+    assert len(SyntheticFrames('allview', img_size=16)) == 23
+    assert len(SyntheticFrames('progress', img_size=16, render_frames=1000)) == 300
+    assert len(SyntheticFrames('movement', img_size=16, render_frames=7)) == 7
+    src = SyntheticFrames('movement', img_size=16, render_frames=3, device_rays=False)
+    batches = list(src)
+    assert len(batches) == 3
+    for k in ('rays', 'near', 'far', 'ray_mask', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'dst_posevec',
+              'cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor', 'img_width', 'frame_name'):
+        assert k in batches[0], k
+    assert batches[0]['rays'].shape[0] == 1 and batches[0]['rays'].shape[1] == 2          # leading batch dimension
+    dev = SyntheticFrames('freeview', img_size=16, render_frames=2, device_rays=True)
+    b = next(iter(dev))
+    assert 'rays' not in b and 'camera_K' in b and 'dst_bbox_min' in b
