@@ -5,13 +5,17 @@ checkpoint), on N MI355X of one node.
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no launcher: bench.py starts the N ranks itself -- a child
+                                       `python -m torch.distributed.run ... bench.py` created before this process
+                                       has touched the GPU -- relays the child's JSON line and exits with its code)
 
 A "step" is one synthetic free-view frame through Network.forward (the reference's module seam), by SURVEY.md
 section 8(d)'s definition of the metric: the frame's ray batch [R,8] and motion-weight prior start in (pinned) host
 memory and are copied to the device inside the step, the [R,5] (rgb, alpha, depth) block is copied back to pinned
 host memory inside the step; PNG encoding is not part of it.  With N > 1 the ONE frame's rays are sharded over the
-ranks (4 096-ray chunks dealt round-robin, occnerf_amd/parallel.py) and the blocks gathered on rank 0 over RCCL --
-the path's only exchange step, issued asynchronously so that frame t's gather runs under frame t+1's kernels:
+ranks (its Morton walk cut into 256-ray blocks, dealt by estimated cost, occnerf_amd/parallel.py) and the blocks
+gathered on rank 0 over RCCL -- the path's only exchange step, issued asynchronously so that frame t's gather runs
+under frame t+1's kernels:
 total work is fixed as N grows (`scaling: strong`); `value` = rays of the frame x steps / wall time (max over
 ranks).  Rank 0 prints ONE JSON line.  `median_ms_per_step` comes from HIP events recorded at every step boundary.
 
@@ -32,7 +36,10 @@ step (forward + backward + clip + Adam, all HIP kernels) on 6 144 rays x 128 sam
 192-sample frame with seeded visibility counts, renderer default and every-live-sample.  `movement` (N = 1): BASELINE
 configs[2]'s sequence on one GPU through the loop run.py executes (occnerf_amd/sequence.py: device ray generation, named
 camera, one frame of lag, device image assembly, uint8 D2H), rays/s over a whole pass.  With N > 1 `config.per_rank_rays` /
-`per_rank_live_samples` show the balance of the shard plan.
+`per_rank_live_samples` show the balance of the shard plan.  `rccl_world1` (N = 1): the same frame through the N > 1
+branch of the sharded renderer with a ONE-rank `nccl` process group (plan + checksum all-gather, padded send buffer,
+asynchronous dist.gather on device buffers, work.wait(), un-permutation): what a single-GPU box can execute of the
+multi-GPU path; pixels bit-identical to the headline's, never part of `value`.
 """
 import argparse
 import json
@@ -71,7 +78,9 @@ def cpu_baseline(ctx, frame, n_rays):
     dt = time.perf_counter() - t0
     return {'value': n_rays / dt, 'unit': 'rays/s', 'cores': os.cpu_count(), 'kind': 'port',
             'sample': f'{n_rays} rays x {SPP} samples of the same 512x512 free-view frame, '
-                      f'oracle/occnerf_oracle.c (OpenMP), {dt:.1f} s'}
+                      f'oracle/occnerf_oracle.c (OpenMP), {dt:.1f} s; a literal serial-fmaf port of the reference\'s '
+                      'arithmetic (the checker: summation order kept so that indices match bit for bit), NOT a tuned CPU '
+                      'implementation -- the GPU/CPU ratio says nothing about kernel quality'}
 
 
 def pmc_traffic(n_samples):
@@ -245,6 +254,55 @@ def movement_leg(net, dev, n_frames=12):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (this
+    process has made no GPU call: a fresh child, never a re-exec), relay rank 0's JSON line, -> the child's exit code."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:                      # (stderr is inherited)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
+def rccl_world1_leg(net, frame_h, dev, steps, want, host_out):
+    """The N > 1 branch of the sharded renderer on the one GPU of this box: a ONE-rank `nccl` (= RCCL) process group,
+    `force_collective`: shard plan from the Morton walk + its checksum all-gather, padded send buffer, asynchronous
+    dist.gather into the list-of-views receive buffer, work.wait(), un-permutation.  Pixels must equal `want` (the
+    headline renderer's [R,5] block) bit for bit."""
+    from occnerf_amd.parallel import ShardedRenderer
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(_free_port()))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        r = ShardedRenderer(net, dev, force_collective=True)
+        dtc, _ = timed_steps(r, frame_h, steps, 2, 0, 1, dev, 'bench', host_out)
+        with torch.no_grad():
+            out = r.finish(r.submit(frame_h, ray_order_key='bench'))['packed']
+        torch.cuda.synchronize()
+        R = out.shape[0]
+        return {'backend': dist.get_backend(), 'world_size_formed': dist.get_world_size(), 'collective': r.collective,
+                'gathers_issued': r.gathers_issued, 'plans_verified': r.plans_verified,
+                'bit_identical_to_headline': bool(torch.equal(out, want)),
+                'value': R * steps / dtc, 'unit': 'rays/s', 'ms_per_step': dtc / steps * 1e3,
+                'note': 'one-rank RCCL group through the N > 1 code path (dist.gather on device buffers); not the headline'}
+    finally:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -253,12 +311,22 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=4096, help='rays in the CPU baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the side measurements (bf16x3, all samples, train)')
+    ap.add_argument('--only', default=None, help='comma-separated side legs to run beside the headline (default: all): '
+                                                 'dedup,rccl_world1,alt,all_samples,train,movement,config4,overlap')
     args = ap.parse_args()
+    only = None if args.only is None else set(args.only.split(','))
 
+    def leg(name):
+        return not args.no_alt and (only is None or name in only)
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:      # no launcher around us: start the ranks ourselves
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('OCC_FORCE_DEVICE', os.environ.get('LOCAL_RANK', 0)))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; start it with '
+                         f'--nproc-per-node {args.gpus}, or without a launcher (bench.py then starts its ranks itself)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     backend = os.environ.get('OCC_DIST_BACKEND', 'nccl')     # 'gloo' + OCC_FORCE_DEVICE=0: dry run of the N > 1 path on one GPU
@@ -313,6 +381,8 @@ def main():
     dt, step_ms = timed_steps(renderer, frame_h, args.steps, 0, rank, world, dev, 'bench', host_out)
     main_events, main_nr = list(mlp_events), list(nr_events)
     ops.canonical_mlp, ops.nonrigid_rows = real_mlp, real_nr
+    torch.cuda.synchronize()
+    headline_out = host_out.clone() if world == 1 else None      # rank 0's [R,5] of the last timed frame
     # balance of the shard plan: rays and live samples every rank rendered in the last frame (read after the timed region)
     my_rays, my_live = renderer.shard_stats()
     per_rank = [[my_rays, my_live if my_live is not None else -1]]
@@ -327,7 +397,7 @@ def main():
         dt = float(tmax[0])
 
     side = {}
-    if not args.no_alt:
+    if leg('dedup'):
         net.cfg.dedup_repeated_samples = True
         if world > 1:
             dist.barrier()
@@ -347,7 +417,13 @@ def main():
                     'much it removes is a property of the frame -- here most live samples sit where the motion-weight sum '
                     'is far below the reference\'s 1e-4 clamp and collapse onto the origin'}
         net.cfg.dedup_repeated_samples = False
-        if world == 1:
+    if world == 1:
+        if leg('rccl_world1'):
+            try:
+                side['rccl_world1'] = rccl_world1_leg(net, frame_h, dev, max(3, args.steps // 2), headline_out.to(dev), host_out)
+            except Exception as e:                                   # a side leg never takes the headline down
+                side['rccl_world1'] = {'error': f'{type(e).__name__}: {e}'[:400]}
+        if leg('alt'):
             # opt-in split-bf16 MLP path (cfg.mlp_precision='bf16x3'): same frame, same steps; never part of `value`
             net.cfg.mlp_precision = 'bf16x3'
             net.invalidate_cache()
@@ -357,6 +433,7 @@ def main():
                            'ms_per_step': dta / args.steps * 1e3}
             net.cfg.mlp_precision = 'fp32'
             net.invalidate_cache()
+        if leg('all_samples'):
             # every sample evaluated (cfg.skip_empty_samples off): same pixels bit for bit
             net.cfg.skip_empty_samples = False
             dtf, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
@@ -366,22 +443,25 @@ def main():
                 'note': 'all R x 128 samples through every stage; the headline drops the samples whose motion-weight '
                         'sum is exactly 0 (alpha is multiplied by it), with bit-identical rgb/alpha/depth'}
             net.cfg.skip_empty_samples = True
+        if leg('train'):
             side['train'] = train_leg(dev, max(5, args.steps // 2), 3)
+        if leg('movement'):
             side['movement'] = movement_leg(net, dev)
+        if leg('config4'):
             del renderer
             torch.cuda.empty_cache()
             side['config4'] = config4_leg(dev)
-        else:
-            # round-1 mode: one whole frame per rank per step, same-size gather (weak scaling)
-            whole = ShardedRenderer(net, dev, single=True)         # every rank renders the full frame by itself
-            dist.barrier()
-            dtw, _ = timed_steps(whole, frame_h, max(3, args.steps // 4), 1, rank, 1, dev, 'bench-whole', host_out)
-            tw = torch.tensor([dtw], device=dev, dtype=torch.float64)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            n = max(3, args.steps // 4)
-            side['weak_frames'] = {'value': world * R * n / float(tw[0]), 'unit': 'rays/s', 'scaling': 'weak',
-                                   'ms_per_step': float(tw[0]) / n * 1e3,
-                                   'note': 'one whole frame per rank per step, no gather (every rank keeps its frame)'}
+    elif leg('weak_frames'):
+        # round-1 mode: one whole frame per rank per step, same-size gather (weak scaling)
+        whole = ShardedRenderer(net, dev, single=True)         # every rank renders the full frame by itself
+        dist.barrier()
+        dtw, _ = timed_steps(whole, frame_h, max(3, args.steps // 4), 1, rank, 1, dev, 'bench-whole', host_out)
+        tw = torch.tensor([dtw], device=dev, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        n = max(3, args.steps // 4)
+        side['weak_frames'] = {'value': world * R * n / float(tw[0]), 'unit': 'rays/s', 'scaling': 'weak',
+                               'ms_per_step': float(tw[0]) / n * 1e3,
+                               'note': 'one whole frame per rank per step, no gather (every rank keeps its frame)'}
 
     if rank == 0:
         ms = [e0.elapsed_time(e1) for e0, e1, _ in main_events]

@@ -17,8 +17,13 @@ samples on every 16th of their rays and dealt serpentine, which brings the ranks
 (tools/shard_balance.py).
 
 The plan is computed by every rank for itself and must come out identical on all of them: it is a pure function of the frame
-and the model (Morton keys, stable sorts, the deterministic sampler/warp kernel on identical devices) -- no collective distributes
-it; ranks on dissimilar GPUs should construct the renderer with `balance=False` (the static deal depends on the rays only).
+and the model (Morton keys, stable sorts, the deterministic sampler/warp kernel on identical devices).  No collective
+distributes it, but one CHECKS it: whenever a plan is built, every rank all-gathers a 3 x 64-bit checksum of it (the ray
+count and per-rank sizes, the Morton walk, the cost order of the blocks) and `finish()` of the first frame rendered with
+the plan raises if any rank disagrees -- a mixed-firmware node or a host frame that differs by one ray is an error, not a
+silently wrong image.  The exchange is asynchronous (device all-gather + pinned copy; `finish` waits on an event that was
+recorded before the frame's kernels), one per NEW plan, not per frame of a named camera.  Ranks on dissimilar GPUs should
+construct the renderer with `balance=False` (the static deal depends on the rays only).
 
 `ShardedRenderer` keeps what does not change from frame to frame -- the shard index lists and the un-permutation
 into the caller's ray order (per `ray_order_key`: a sequence shot by one camera names it, as `Network.forward`'s
@@ -26,6 +31,8 @@ Morton cache does), padded send / receive buffers in two slots -- and issues the
 t's gather runs under frame t+1's kernels (`render_frames`).  A rank whose shard is empty (fewer blocks than ranks)
 skips the render and still takes part in the gather.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -108,19 +115,31 @@ class ShardedRenderer:
     """Renders frames with their rays sharded over the ranks of `group` (see the module docstring)."""
 
     def __init__(self, net, device, group=None, block=BLOCK, channels=5, single=False, morton=True, chunk=None,
-                 balance=True):
+                 balance=True, force_collective=None, verify_plan=True):
         """single: ignore the process group, this process renders whole frames by itself.  morton=False deals the
         caller's own ray order.  balance=False: static dealing (block b -> rank b % N) even when the network can
-        estimate block costs.  chunk: older name of `block`."""
+        estimate block costs.  chunk: older name of `block`.  force_collective (default: env OCC_FORCE_COLLECTIVE=1): a
+        process group of ONE rank still takes the N > 1 branch -- Morton-block plan, padded send buffer, asynchronous
+        `dist.gather` into the list-of-views receive buffer, `work.wait()`, un-permutation -- so that the RCCL path runs on
+        a single-GPU box exactly as it does on a node.  verify_plan=False skips the plan checksum exchange."""
         self.net, self.device, self.group, self.channels = net, torch.device(device), group, channels
         self.block = int(chunk if chunk is not None else block)
         self.morton = bool(morton)
         self.balance = bool(balance)
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() and not single else 1
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        formed = dist.is_available() and dist.is_initialized() and not single
+        self.world = dist.get_world_size(group) if formed else 1
+        self.rank = dist.get_rank(group) if formed else 0
+        if force_collective is None:
+            force_collective = os.environ.get('OCC_FORCE_COLLECTIVE', '0') == '1'
+        # collective: this renderer exchanges blocks through the process group (always when it has more than one rank)
+        self.collective = bool(formed and (self.world > 1 or force_collective))
+        self.verify_plan = bool(verify_plan)
+        self.backend = dist.get_backend(group) if formed else None
         # gloo has no gather on device tensors: with that backend (tests: several processes sharing one GPU) the blocks
         # are exchanged through host buffers; with nccl (= RCCL) they stay on the device
-        self.host_exchange = self.world > 1 and self.device.type == 'cuda' and dist.get_backend(group) == 'gloo'
+        self.host_exchange = self.collective and self.device.type == 'cuda' and self.backend == 'gloo'
+        self.gathers_issued = 0          # dist.gather calls issued (what bench.py / the tests report)
+        self.plans_verified = 0          # plan checksums exchanged and found equal on every rank
         self._plans = {}          # (rays per frame, ray_order_key) -> shard plan (index lists)
         self._bufs = {}           # padded width -> send / receive / staging buffers, two slots
         self._turn = 0
@@ -131,7 +150,7 @@ class ShardedRenderer:
         return self.world
 
     # ------------------------------------------------------------------ plans and buffers
-    def _block_costs(self, data, order, nb_full):
+    def _block_costs(self, data, order, nb_full, iter_val=1e7):
         """Estimated cost of every full block of the walk: live samples on 16 of its rays (`Network.live_samples_per_ray`:
         the frame's preamble + the sampler/warp kernel on a sixteenth of the rays, ~0.3 ms for a 512^2 frame).  Every rank
         computes the same numbers from the same frame.  None when the network cannot tell (the plan is then static)."""
@@ -143,19 +162,68 @@ class ShardedRenderer:
         p = (torch.arange(nb_full * per, device=order.device) * PROBE_STRIDE + PROBE_STRIDE // 2)
         idx = order[p]
         sub = {k: v for k, v in data.items() if k not in ('rays', 'near', 'far')}
-        live = probe(rays=data['rays'][:, idx], near=data['near'].reshape(-1, 1)[idx], far=data['far'].reshape(-1, 1)[idx], **sub)
+        live = probe(rays=data['rays'][:, idx], near=data['near'].reshape(-1, 1)[idx], far=data['far'].reshape(-1, 1)[idx],
+                     iter_val=iter_val, **sub)      # (the iteration decides whether the pose refiner is on: same warp as the render)
         return live.view(nb_full, per).sum(dim=1).to(order.device)      # (host frames: one read per plan)
 
-    def _build_plan(self, data):
+    @staticmethod
+    def _mix64(t):
+        """Order-sensitive 64-bit checksum of an integer tensor (int64 arithmetic wraps): sum of (t_i + 1) * odd(i)."""
+        t = t.to(torch.int64)
+        i = torch.arange(t.numel(), device=t.device, dtype=torch.int64)
+        return ((t + 1) * (i * -7046029254386353131 + 0x2545F4914F6CDD1D | 1)).sum()
+
+    def _start_plan_check(self, plan, order, by_cost):
+        """All-gather the plan's checksum [R / sizes, walk, cost order]; verified by the first `finish()` that uses the plan."""
+        if not (self.collective and self.verify_plan):
+            return
+        meta = torch.tensor([plan['R'], plan['width'], int(plan['cost_aware'])] + list(plan['sizes']), dtype=torch.int64)
+        where = order.device
+        mine = torch.stack([self._mix64(meta).to(where), self._mix64(order), self._mix64(by_cost)])
+        W = self.world
+        if self.backend == 'nccl':
+            mine = mine.to(self.device)
+            allc = torch.empty(W * 3, dtype=torch.int64, device=self.device)
+            work = dist.all_gather_into_tensor(allc, mine, group=self.group, async_op=True)
+            work.wait()                                   # stream-level: the copy below is ordered after the collective
+            host = torch.empty(W * 3, dtype=torch.int64).pin_memory()
+            host.copy_(allc, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            plan['check'] = (ev, host, allc)
+        else:                                             # gloo (CPU tests, ranks sharing a GPU): host tensors, synchronous
+            parts = [torch.empty(3, dtype=torch.int64) for _ in range(W)]
+            dist.all_gather(parts, mine.cpu(), group=self.group)
+            plan['check'] = (None, torch.cat(parts), None)
+
+    def _verify_plan(self, plan):
+        chk = plan.get('check')
+        if chk is None:
+            return
+        ev, host, _ = chk
+        if ev is not None:
+            ev.synchronize()
+        rows = host.view(self.world, 3)
+        bad = [r for r in range(self.world) if not torch.equal(rows[r], rows[self.rank])]
+        plan['check'] = None
+        if bad:
+            what = ['ray count / shard sizes', 'Morton walk', 'cost order of the blocks']
+            diff = sorted({what[c] for r in bad for c in range(3) if rows[r, c] != rows[self.rank, c]})
+            raise RuntimeError(f'shard plan of rank {self.rank} differs from rank(s) {bad} in: {", ".join(diff)} -- the '
+                               'ranks were handed different frames or computed different block costs (dissimilar GPUs: '
+                               'construct ShardedRenderer with balance=False)')
+        self.plans_verified += 1
+
+    def _build_plan(self, data, iter_val=1e7):
         rays = data['rays']
         R, W, B = int(rays.shape[1]), self.world, self.block
         nb_full, tail = divmod(R, B)
         nb = nb_full + (1 if tail else 0)
-        if W == 1:
+        if not self.collective:
             return {'R': R, 'sizes': [R], 'width': -(-max(R, 1) // WIDTH_QUANTUM) * WIDTH_QUANTUM}
         where = rays.device
         order = ray_patch_order(rays[1]) if self.morton else torch.arange(R, device=where)   # [R] walk position -> ray index
-        cost = self._block_costs(data, order, nb_full) if self.morton else None
+        cost = self._block_costs(data, order, nb_full, iter_val) if self.morton else None
         serp = cost is not None
         # Dealing position s of a block: its index in the walk (static plan), or its place in the descending order of the
         # estimated costs (cost-aware plan; the partial tail block always last).  Position s goes to rank s % W -- every
@@ -195,18 +263,19 @@ class ShardedRenderer:
             src = torch.empty_like(dest)
             src[order] = dest
             plan['unpermute'] = src.to(self.device)
+        self._start_plan_check(plan, order, by_cost)
         return plan
 
-    def _get_plan(self, data, key):
+    def _get_plan(self, data, key, iter_val=1e7):
         R = int(data['rays'].shape[1])
-        if key is None and self.world > 1 and self.morton:
-            return self._build_plan(data)                         # unnamed camera: the walk is recomputed for this frame
+        if key is None and self.collective and self.morton:
+            return self._build_plan(data, iter_val)               # unnamed camera: the walk is recomputed for this frame
         k = (R, key)
         hit = self._plans.get(k)
         if hit is None:
             if len(self._plans) >= 16:                            # a sequence's frames differ in ray count: keep a few plans
                 self._plans.pop(next(iter(self._plans)))
-            hit = self._plans[k] = self._build_plan(data)
+            hit = self._plans[k] = self._build_plan(data, iter_val)
         return hit
 
     def _mine(self, plan, dev_type):
@@ -226,7 +295,7 @@ class ShardedRenderer:
                 b['send_host'] = [torch.zeros(width, self.channels).pin_memory() for _ in range(2)]
                 if self.rank == 0:
                     b['recv_host'] = [torch.empty(self.world * width, self.channels).pin_memory() for _ in range(2)]
-            if self.rank == 0 and self.world > 1:
+            if self.rank == 0 and self.collective:
                 b['recv'] = [torch.empty(self.world * width, self.channels, device=self.device) for _ in range(2)]
             b['gpu'] = gpu
             self._bufs[width] = b
@@ -240,7 +309,7 @@ class ShardedRenderer:
         key and ray count reuse the shard plan (and, inside `Network`, the Morton order of the shard)."""
         rays = data['rays']
         R = int(rays.shape[1])
-        plan = self._get_plan(data, ray_order_key)
+        plan = self._get_plan(data, ray_order_key, iter_val)
         bufs = self._get_bufs(plan['width'])
         slot = self._turn = self._turn ^ 1
         n_mine = plan['sizes'][self.rank]
@@ -248,7 +317,7 @@ class ShardedRenderer:
         send = bufs['send'][slot]
         if n_mine:
             local = dict(data)
-            if self.world == 1:                                  # the whole frame is this rank's
+            if not self.collective:                              # the whole frame is this rank's, in the caller's order
                 sub = (rays, data['near'], data['far'])
             elif rays.is_cuda:
                 mine = self._mine(plan, 'cuda')
@@ -257,13 +326,16 @@ class ShardedRenderer:
                 mine = self._mine(plan, 'cpu')                   # that the copies below really are asynchronous
                 if bufs['stage'][slot] is None:
                     w = plan['width']
-                    st = [torch.empty(2, w, 3), torch.empty(w, 1), torch.empty(w, 1)]
+                    st = [torch.empty(2 * w * 3), torch.empty(w, 1), torch.empty(w, 1)]
                     bufs['stage'][slot] = tuple(b.pin_memory() if bufs['gpu'] else b for b in st) + \
                         (torch.cuda.Event() if bufs['gpu'] else None,)
                 rs, ns, fs, ev = bufs['stage'][slot]
                 if ev is not None:
                     ev.synchronize()                             # the copy issued from this slot two frames ago has left it
-                rs, ns, fs = rs[:, :n_mine], ns[:n_mine], fs[:n_mine]
+                # the rays stage is FLAT and viewed as [2, n_mine, 3]: a slice [:, :n_mine] of a [2, w, 3] buffer is not
+                # contiguous, and .to(device) of a non-contiguous pinned tensor goes through a pageable temporary
+                # (a synchronous copy)
+                rs, ns, fs = rs[:2 * n_mine * 3].view(2, n_mine, 3), ns[:n_mine], fs[:n_mine]
                 torch.index_select(rays, 1, mine, out=rs)
                 torch.index_select(data['near'].reshape(-1, 1), 0, mine, out=ns)
                 torch.index_select(data['far'].reshape(-1, 1), 0, mine, out=fs)
@@ -271,7 +343,7 @@ class ShardedRenderer:
             local['rays'] = sub[0].to(self.device, non_blocking=True)
             local['near'] = sub[1].to(self.device, non_blocking=True)
             local['far'] = sub[2].to(self.device, non_blocking=True)
-            if self.world > 1 and not rays.is_cuda and bufs['stage'][slot][3] is not None:
+            if self.collective and not rays.is_cuda and bufs['stage'][slot][3] is not None:
                 bufs['stage'][slot][3].record(torch.cuda.current_stream(self.device))
             for k, v in data.items():
                 if k not in ('rays', 'near', 'far') and torch.is_tensor(v) and not v.is_cuda and v.numel() > 3:
@@ -282,7 +354,7 @@ class ShardedRenderer:
             send[:n_mine, :3] = out['rgb']
             send[:n_mine, 3] = out['alpha']
             send[:n_mine, 4] = out['depth']
-        if self.world == 1:
+        if not self.collective:
             return _Pending(None, slot, R, plan, bufs)
         if self.host_exchange:
             send = bufs['send_host'][slot].copy_(send)               # (synchronous: the gloo path is a test vehicle)
@@ -291,16 +363,18 @@ class ShardedRenderer:
             rbuf = bufs['recv'][slot] if self.rank == 0 else None
         recv = list(rbuf.view(self.world, plan['width'], self.channels).unbind(0)) if self.rank == 0 else None
         work = dist.gather(send, recv, dst=0, group=self.group, async_op=True)
+        self.gathers_issued += 1
         return _Pending(work, slot, R, plan, bufs)
 
     def finish(self, pending):
         """Wait for a frame's gather; -> {'rgb','alpha','depth'} in the caller's ray order on rank 0, None elsewhere.
         The tensors are the frame's own (not views of the slot buffers, which the frame after next reuses)."""
         plan, bufs = pending.plan, pending.bufs
-        if self.world == 1:
+        if not self.collective:
             full = bufs['send'][pending.slot][:pending.n_rays].clone()
         else:
             pending.work.wait()
+            self._verify_plan(plan)
             if self.rank != 0:
                 return None
             if self.host_exchange:

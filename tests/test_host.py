@@ -101,7 +101,7 @@ def test_morton_plan_matches_positions():
     seen = []
     for rank in range(W):
         r = ShardedRenderer(None, 'cpu', block=B, single=True)
-        r.world, r.rank = W, rank                                    # plan arithmetic only: no process group needed
+        r.world, r.rank, r.collective, r.verify_plan = W, rank, True, False                                    # plan arithmetic only: no process group needed
         plan = r._build_plan({'rays': rays})
         mine = plan['mine']['cpu']
         want = torch.cat([order[b * B:(b + 1) * B] for b in range(rank, -(-R // B), W)])
@@ -136,7 +136,7 @@ def test_cost_aware_plan_balances_live_samples():
         parts, sums = [], []
         for rank in range(W):
             r = ShardedRenderer(CostNet(), 'cpu', block=B, single=True, balance=balance)
-            r.world, r.rank = W, rank
+            r.world, r.rank, r.collective, r.verify_plan = W, rank, True, False
             plan = r._build_plan(data)
             assert plan['cost_aware'] == balance
             mine = plan['mine']['cpu']
@@ -228,3 +228,77 @@ def test_ray_sharding_gather_gloo(n_rays, world):
         p.join(timeout=60)
         assert p.exitcode == 0
 
+
+
+class _FakeNet:                                           # renders rgb = f(ray) per ray, no coupling
+    def __call__(self, rays, near, far, iter_val=0, **_):
+        return {'rgb': rays[0] * 2.0, 'alpha': near[:, 0] + 1.0, 'depth': far[:, 0] * 3.0}
+
+    def live_samples_per_ray(self, rays, near, far, **_):
+        return (rays[1, :, 0] * 50).long() + 1
+
+
+def _plan_worker(rank, world, port, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from occnerf_amd.parallel import ShardedRenderer
+    g = torch.Generator().manual_seed(3)
+    n = 1500
+    data = {'rays': torch.rand(2, n, 3, generator=g), 'near': torch.rand(n, 1, generator=g), 'far': torch.rand(n, 1, generator=g)}
+    ok = True
+    if mode == 'force1':
+        # a process group of ONE rank takes the N > 1 branch: plan, padded buffers, dist.gather, work.wait(), un-permutation
+        r = ShardedRenderer(_FakeNet(), 'cpu', chunk=96, force_collective=True)
+        assert r.collective and r.world == 1 and not ShardedRenderer(_FakeNet(), 'cpu', chunk=96).collective
+        frames = [({k: v[..., :n - 11 * t, :] if k == 'rays' else v[:n - 11 * t] for k, v in data.items()},
+                   ('cam', t % 2)) for t in range(5)]
+        outs = list(r.render_frames(frames))
+        for o, (d, _) in zip(outs, frames):
+            ok = ok and torch.equal(o['rgb'], d['rays'][0] * 2.0) and torch.equal(o['alpha'], d['near'][:, 0] + 1.0) \
+                and torch.equal(o['depth'], d['far'][:, 0] * 3.0)
+        ok = ok and r.gathers_issued == 5 and r.plans_verified == 5       # (five different ray counts: five plans)
+    else:
+        mine = dict(data)
+        if rank == 1 and mode == 'one_ray_less':
+            mine = {'rays': data['rays'][:, :-1], 'near': data['near'][:-1], 'far': data['far'][:-1]}
+        if rank == 1 and mode == 'one_ray_moved':
+            mine['rays'] = data['rays'].clone()
+            mine['rays'][1, 700] = torch.tensor([5., -5., 0.1])
+        if rank == 1 and mode == 'costs_differ':
+            class Other(_FakeNet):
+                def live_samples_per_ray(self, rays, near, far, **_):
+                    return (rays[1, :, 1] * 50).long() + 1
+            net = Other()
+        else:
+            net = _FakeNet()
+        r = ShardedRenderer(net, 'cpu', chunk=96)
+        try:
+            r.finish(r.submit(mine))
+            ok = mode == 'same'
+        except RuntimeError as e:
+            want = {'one_ray_less': 'ray count', 'one_ray_moved': 'Morton walk', 'costs_differ': 'cost order'}[mode]
+            ok = want in str(e) and 'differs from rank' in str(e)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode,world', [('force1', 1), ('same', 2), ('one_ray_less', 2), ('one_ray_moved', 2),
+                                        ('costs_differ', 2)])
+def test_forced_collective_and_plan_checksum_gloo(mode, world):
+    """(a) with force_collective a ONE-rank process group runs the real gather branch (what a single-GPU box
+    can execute of the RCCL path); (c) every rank all-gathers a checksum of each new shard plan and `finish` raises on ALL
+    ranks when they disagree -- a frame that differs by one ray, a ray that sits elsewhere in the Morton walk, a
+    different cost estimate -- instead of assembling a wrong image."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    assert got == {r: True for r in range(world)}, (mode, got)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0

@@ -39,7 +39,7 @@ def main():
             rows = []
             for rank in range(W):
                 r = ShardedRenderer(net, dev, block=args.block, single=True, morton=not args.no_morton, balance=not args.static)
-                r.world, r.rank = W, rank                                # plan arithmetic only
+                r.world, r.rank, r.collective, r.verify_plan = W, rank, True, False                                # plan arithmetic only
                 plan = r._build_plan(data)
                 sub = dict(data)
                 if W > 1:

@@ -4,6 +4,8 @@ frames of different poses (host frames); `--kind movement --size 512 --spp 128 -
 the movement pose walk from one camera, rays generated on the device, camera named (cached shard plans).
 With OCC_DIST_BACKEND=gloo OCC_FORCE_DEVICE=0 the ranks share one GPU and exchange through the host (RCCL refuses two
 ranks on one device): everything but the collective itself is then the production code path.
+`--force-collective` with ONE rank (`--nproc-per-node 1`, nccl): the one-rank RCCL group takes the N > 1 branch -- plan
+checksum all-gather, dist.gather on device buffers, work.wait(), un-permutation -- which a single-GPU box can execute.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tools/sharded_check.py
 """
 import json
@@ -23,6 +25,7 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--spp', type=int, default=64)
     ap.add_argument('--frames', type=int, default=3)
+    ap.add_argument('--force-collective', action='store_true')
     args = ap.parse_args()
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
     local = int(os.environ.get('OCC_FORCE_DEVICE', local))        # experiment: several ranks on one GPU
@@ -51,7 +54,8 @@ def main():
             d.update(rays=fr['rays'], near=fr['near'], far=fr['far'])
             frames.append((d, ('movement', int(fr['rays'].shape[1]))))
     with torch.no_grad():
-        sharded = list(ShardedRenderer(net, dev).render_frames(frames))
+        sr = ShardedRenderer(net, dev, force_collective=args.force_collective or None)
+        sharded = list(sr.render_frames(frames))
         ok, worst = True, 0.0
         if rank == 0:
             alone = list(ShardedRenderer(net, dev, single=True).render_frames(frames))
@@ -59,7 +63,8 @@ def main():
                 for k in ('rgb', 'alpha', 'depth'):
                     ok = ok and torch.equal(a[k], b[k])
                     worst = max(worst, float((a[k] - b[k]).abs().max()))
-            print(json.dumps({'world_size_formed': dist.get_world_size(), 'backend': backend, 'frames': len(frames), 'bit_identical': bool(ok),
+            print(json.dumps({'world_size_formed': dist.get_world_size(), 'backend': backend, 'collective': sr.collective,
+                              'gathers_issued': sr.gathers_issued, 'plans_verified': sr.plans_verified, 'frames': len(frames), 'bit_identical': bool(ok),
                               'max_abs_diff': worst, 'kind': args.kind, 'size': args.size, 'spp': args.spp,
                               'rays': [int((f[0] if isinstance(f, tuple) else f)['rays'].shape[1]) for f in frames]}))
     dist.barrier()
