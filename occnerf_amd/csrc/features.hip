@@ -1135,7 +1135,9 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                                      dense ? r1 * r1 * r1 : 3674653429u, 0u};
         }
         OCC_REQUIRE(P > 0, "sample_features: P=%d rows of packed point records", P);
-        const bool lds_tail = P <= kLdsTailPoints && N >= 96 * 64;      // (small calls: not worth a 110 KiB image per block)
+        const char *small_env = getenv("OCCNERF_FEATURES_SMALL");      // experiment: 4-wave workgroups, counts from L2
+        const bool force_small = small_env && small_env[0] == '1';
+        const bool lds_tail = P <= kLdsTailPoints && N >= 96 * 64 && !force_small;      // (small calls: not worth a 110 KiB image per block)
         const int threads = lds_tail ? 768 : 256;
         int64_t blocks8 = (N * 8 + threads - 1) / threads;
         const int64_t cap = lds_tail ? (int64_t)kNumCU : (int64_t)kNumCU * 32;
@@ -1154,7 +1156,14 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
         }
         auto kern = generic ? (lds_tail ? sample_features8_kernel<true, true> : sample_features8_kernel<true, false>)
                             : (lds_tail ? sample_features8_kernel<false, true> : sample_features8_kernel<false, false>);
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks8), dim3(threads), 0, as_stream(stream), xyz,
+        const char *cohab_env = getenv("OCCNERF_COHAB_LDS");       // experiment, see msknn_clustered
+        const unsigned cohab_lds = (cohab_env && !lds_tail) ? (unsigned)atoi(cohab_env) : 0u;
+        if (cohab_lds) {
+            if (blocks8 > (int64_t)kNumCU) blocks8 = kNumCU;
+            OCC_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)cohab_lds) == hipSuccess, "sample_features: hipFuncSetAttribute");
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks8), dim3(threads), cohab_lds, as_stream(stream), xyz,
                            N, knn_idxs, reinterpret_cast<const float4 *>(point_geo),
                            reinterpret_cast<const float4 *>(point_tail),
                            reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),

@@ -546,6 +546,16 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t
     OCC_REQUIRE(tiles < (1ll << 31), "msknn_clustered: too many tiles for one launch");
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > (int64_t)kNumCU * 3) blocks = (int64_t)kNumCU * 3;      // 12 resident waves per CU at this register count
+    // experiment (OCCNERF_COHAB_LDS=<bytes>): one workgroup per CU, padded with unused LDS so that a CU holds at most one of
+    // them and exactly one canonical-MLP workgroup (78 112 B) beside it
+    const char *cohab_env = getenv("OCCNERF_COHAB_LDS");
+    const unsigned cohab_lds = cohab_env ? (unsigned)atoi(cohab_env) : 0u;
+    if (cohab_lds) {
+        if (blocks > (int64_t)kNumCU) blocks = kNumCU;
+        OCC_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(msknn_clustered_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)cohab_lds) == hipSuccess,
+                    "msknn_clustered: hipFuncSetAttribute");
+    }
     // ticket counter of this launch: a slot of a small per-device ring, zeroed on the launch stream
     static std::mutex mu;
     static unsigned *ring[16] = {nullptr};
@@ -562,7 +572,7 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t
     if (query_rows)
         hipLaunchKernelGGL(ray_list_ranges_kernel, dim3((unsigned)((n_rays + 256) / 256)), dim3(256), 0, as_stream(stream),
                            query_rows, n_query_dev, n_rays, samples_per_ray, ray_start);
-    hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, mask,
+    hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), cohab_lds, as_stream(stream), xyz, mask,
                        n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points),
                        reinterpret_cast<const float4 *>(centers), reinterpret_cast<const int2 *>(cluster_ranges),
                        cluster_radius, reinterpret_cast<const float4 *>(group_centers),

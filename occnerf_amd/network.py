@@ -234,6 +234,103 @@ class Network(nn.Module):
         return table
 
     # ------------------------------------------------------------------ sample pipeline
+    def _stage_features(self, rays8, z, xyz, mask, pk, cond, hann, table, pack):
+        """First half of a pass on the live-sample list (VALU / texture-path kernels + the non-rigid MLP): live list, non-rigid
+        offsets, repeated-sample heads, kNN, features.  -> state for `_stage_mlp_composite`.  List and count of the live samples
+        stay on the device: no host round trip in the frame."""
+        cfg, ctx = self.cfg, self._context()
+        S = int(cfg.N_samples)
+        enc = self.cnl_mlp.module.encoder
+        rows, count = ops.live_rows(mask)
+        self.last_live_count = count
+        dedup = bool(cfg.get('dedup_repeated_samples', True))
+        # Repeated samples (ops.repeat_heads): consecutive live samples with a bitwise identical canonical position
+        # share the neighbour search and the features, consecutive feature rows that are bitwise identical share the
+        # MLP result.
+        # Each distinct input is evaluated once and every sample receives its head's result: bit-identical pixels
+        # (cfg.dedup_repeated_samples=False evaluates every live sample; tested).
+        scan_a = scan_b = mrows = mcount = None
+        frows, fcount, kmask = rows, count, mask
+        if not cfg.ignore_non_rigid_motions:
+            ops.nonrigid_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
+        if dedup:       # (the positions before the offset differ in their last bits; after it they coincide)
+            scan_a, frows, fcount, kmask = ops.repeat_heads(xyz, 3, count, rows=rows,
+                                                            want_mask=not cfg.get('knn_query_list', True))
+            # (the positions' repeats that are not neighbours in the list are few -- 9.28 M -> 8.39 M on the benchmark
+            # frame -- and finding them, 1.7 ms, costs more than the kNN + feature work they save, 0.6 ms)
+            if cfg.get('dedup_global_positions', False):
+                frows, fcount = ops.unique_heads(xyz, 3, frows, fcount, scan=scan_a, scan_count=count)
+        self.last_head_counts = (fcount, None)
+        if cfg.get('knn_query_list', True):    # tiles formed over the listed samples only (same indices, tested)
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], rows=frows, count=fcount)
+        else:
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=kmask)
+        mlp_in, raw_c, _ = ops.sample_features(
+            xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
+            self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
+            enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution,
+            rows=frows, count=fcount, pack=pack)
+        del knn
+        if dedup:
+            scan_b, mrows, mcount, _ = ops.repeat_heads(mlp_in, 68, fcount)
+            if cfg.get('dedup_global', True):       # ... and the repeats that are not neighbours in the list
+                mrows, mcount = ops.unique_heads(mlp_in, 68, mrows, mcount, scan=scan_b, scan_count=fcount)
+            self.last_head_counts = (fcount, mcount)
+        return {'dedup': dedup, 'rays8': rays8, 'z': z, 'mask': mask, 'rows': rows, 'count': count, 'mlp_in': mlp_in,
+                'raw_c': raw_c, 'scan_a': scan_a, 'scan_b': scan_b, 'mrows': mrows, 'mcount': mcount, 'cnl': pk['cnl'],
+                'N': xyz.shape[0]}
+
+    @staticmethod
+    def _stage_mlp_composite(st, bgcolor, out, out_rows):
+        """Second half of a pass (the matrix-pipe kernel + the per-ray scan): canonical MLP on the feature rows, results back
+        to their samples, alpha compositing into the frame's rows."""
+        dev, N = st['mlp_in'].device, st['N']
+        if st['dedup']:
+            raw_h = torch.empty(st['mlp_in'].shape[0], 5, device=dev)
+            ops.canonical_mlp(st['mlp_in'], st['cnl'], raw_h, count=st['mcount'], in_rows=st['mrows'])
+            raw = ops.scatter_raw_heads(raw_h, st['raw_c'], st['rows'], st['count'], st['scan_a'], st['scan_b'],
+                                        torch.zeros(N, 5, device=dev))
+        else:
+            ops.canonical_mlp(st['mlp_in'], st['cnl'], st['raw_c'], count=st['count'])
+            raw = ops.scatter_raw(st['raw_c'], st['rows'], st['count'], torch.zeros(N, 5, device=dev))
+        st['mlp_in'] = None
+        return ops.composite(raw, st['mask'], st['z'], st['rays8'], bgcolor, out=out, out_rows=out_rows)[:3]
+
+    def _side_stream(self, dev):
+        """The producer stream of the overlapped render (high priority: its small VALU / texture-path workgroups take the
+        slots the matrix-pipe kernel's retiring workgroups free)."""
+        s = getattr(self, '_producer', None)
+        if s is None or s.device != dev:
+            s = self._producer = torch.cuda.Stream(device=dev, priority=int(os.environ.get('OCC_PRODUCER_PRIORITY', '-1')))
+        return s
+
+    def _render_overlapped(self, chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, table, pack):
+        """The frame's rays in `chunks` = [(rays8 slice, out_rows slice or None, out tensors)], software-pipelined over two streams: chunk k + 1's
+        sampler / warp / non-rigid MLP / kNN / feature kernels (producer stream) run while chunk k's canonical MLP and
+        compositing do (the caller's stream).  The kNN kernel is VALU-bound and the feature kernel texture-path-bound; the
+        canonical MLP leaves both almost idle (and they leave the matrix pipe idle), so the two halves fill different units
+        of the same CUs.  Same kernels on the same inputs as the serial order: bit-identical pixels (tested)."""
+        cfg = self.cfg
+        S = int(cfg.N_samples)
+        dev = chunks[0][0].device
+        main, prod = torch.cuda.current_stream(dev), self._side_stream(dev)
+        pk = self._packed_weights()
+        t_vals = torch.linspace(0., 1., steps=S, device=dev)
+        prod.wait_stream(main)
+        for rays8, out_rows, out in chunks:
+            with torch.cuda.stream(prod):
+                z, xyz, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale)
+                st = self._stage_features(rays8, z, xyz, mask, pk, cond, hann, table, pack)
+                del xyz
+                ready = prod.record_event()
+            main.wait_event(ready)
+            for v in st.values():                    # produced on `prod`, consumed (and released) on `main`
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)
+            self._stage_mlp_composite(st, bgcolor, out, out_rows)
+            del st
+        # (nothing to join: the consumer stream is the caller's, and every producer kernel precedes a consumer wait)
+
     def _render_rays(self, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann,
                      table, t_rand=None, out=None, out_rows=None, pack=None):
         """out: (rgb[R,3], alpha[R], depth[R]) of the whole frame; this pass's rays land in rows out_rows (their index
@@ -252,52 +349,8 @@ class Network(nn.Module):
         N = xyz.shape[0]
         fp32 = pk['cnl_bf16'] is None and pk['nr_bf16'] is None
         if cfg.get('skip_empty_samples', True) and cfg.get('knn_culling', True) and fp32:
-            # list and count of the live samples stay on the device: no host round trip in the frame
-            rows, count = ops.live_rows(mask)
-            self.last_live_count = count
-            dev = xyz.device
-            dedup = bool(cfg.get('dedup_repeated_samples', True))
-            # Repeated samples (ops.repeat_heads): consecutive live samples with a bitwise identical canonical position
-            # share the neighbour search and the features, consecutive feature rows that are bitwise identical share the
-            # MLP result.
-            # Each distinct input is evaluated once and every sample receives its head's result: bit-identical pixels
-            # (cfg.dedup_repeated_samples=False evaluates every live sample; tested).
-            scan_a = scan_b = None
-            frows, fcount, kmask = rows, count, mask
-            if not cfg.ignore_non_rigid_motions:
-                ops.nonrigid_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
-            if dedup:       # (the positions before the offset differ in their last bits; after it they coincide)
-                scan_a, frows, fcount, kmask = ops.repeat_heads(xyz, 3, count, rows=rows,
-                                                                want_mask=not cfg.get('knn_query_list', True))
-                # (the positions' repeats that are not neighbours in the list are few -- 9.28 M -> 8.39 M on the benchmark
-                # frame -- and finding them, 1.7 ms, costs more than the kNN + feature work they save, 0.6 ms)
-                if cfg.get('dedup_global_positions', False):
-                    frows, fcount = ops.unique_heads(xyz, 3, frows, fcount, scan=scan_a, scan_count=count)
-            self.last_head_counts = (fcount, None)
-            if cfg.get('knn_query_list', True):    # tiles formed over the listed samples only (same indices, tested)
-                knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], rows=frows, count=fcount)
-            else:
-                knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=kmask)
-            mlp_in, raw_c, _ = ops.sample_features(
-                xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
-                self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
-                enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution,
-                rows=frows, count=fcount, pack=pack)
-            del knn
-            if dedup:
-                scan_b, mrows, mcount, _ = ops.repeat_heads(mlp_in, 68, fcount)
-                if cfg.get('dedup_global', True):       # ... and the repeats that are not neighbours in the list
-                    mrows, mcount = ops.unique_heads(mlp_in, 68, mrows, mcount, scan=scan_b, scan_count=fcount)
-                self.last_head_counts = (fcount, mcount)
-                raw_h = torch.empty(mlp_in.shape[0], 5, device=dev)
-                ops.canonical_mlp(mlp_in, pk['cnl'], raw_h, count=mcount, in_rows=mrows)
-                del mlp_in
-                raw = ops.scatter_raw_heads(raw_h, raw_c, rows, count, scan_a, scan_b, torch.zeros(N, 5, device=dev))
-            else:
-                ops.canonical_mlp(mlp_in, pk['cnl'], raw_c, count=count)
-                del mlp_in
-                raw = ops.scatter_raw(raw_c, rows, count, torch.zeros(N, 5, device=dev))
-            return ops.composite(raw, mask, z, rays8, bgcolor, out=out, out_rows=out_rows)[:3]
+            st = self._stage_features(rays8, z, xyz, mask, pk, cond, hann, table, pack)
+            return self._stage_mlp_composite(st, bgcolor, out, out_rows)
 
         # split-bf16 kernels (opt-in) take the list through the host: one nonzero = one sync
         rows = None
@@ -440,7 +493,16 @@ class Network(nn.Module):
                 out = (torch.empty(R, 3, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev))
                 # all rays of the frame in as few passes as memory allows
                 rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 28)) // S)
-                for i in range(0, R, rays_per_pass):
+                n_over = int(cfg.get('overlap_chunks', 0))
+                overlap = (n_over > 1 and R >= n_over * 1024 and cfg.get('skip_empty_samples', True) and
+                           cfg.get('knn_culling', True) and cfg.get('mlp_precision', 'fp32') != 'bf16x3')
+                if overlap:      # chunks of whole 256-ray blocks (four kNN tiles), two streams (see _render_overlapped)
+                    per = min(rays_per_pass, -(-R // (n_over * 256)) * 256)
+                    chunks = [(rays8[i:i + per], None if order is None else order[i:i + per],
+                               out if order is not None else tuple(t[i:i + per] for t in out)) for i in range(0, R, per)]
+                    self._render_overlapped(chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
+                                            wc['table'], pack)
+                for i in range(0, 0 if overlap else R, rays_per_pass):
                     n = min(rays_per_pass, R - i)
                     if order is not None:
                         self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),

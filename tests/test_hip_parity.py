@@ -936,6 +936,33 @@ def test_skip_empty_samples_is_exact_at_bench_size(ops):
         assert torch.equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize('dedup', [False, True])
+def test_overlapped_render_is_exact_at_bench_size(ops, dedup):
+    """cfg.overlap_chunks (Network._render_overlapped: chunk k + 1's sampler / non-rigid / kNN / feature kernels on a second
+    stream under chunk k's canonical MLP; opt-in, measured neutral -- profiles/r04_summary.md) runs the same kernels on the
+    same inputs: the benchmark frame in 3 and 5 chunks is bit-identical to the serial render, with and without the
+    elimination of repeated samples, and so is a second frame rendered right behind it (buffers crossing streams)."""
+    from occnerf_amd import synth
+    net, ctx = build_network(seed=0, amplify=False, S=128, non_rigid=True)
+    net.cfg.dedup_repeated_samples = dedup
+    frames = [frame_to_device(synth.make_frame(img_size=512, pose72=synth.seeded_pose(1 + t), orbit_frame=28 + 9 * t), DEV)
+              for t in range(2)]
+    ref = None
+    try:
+        for chunks in (0, 3, 5):
+            net.cfg.overlap_chunks = chunks
+            with torch.no_grad():
+                outs = [net(**d, iter_val=1e7) for d in frames]       # back to back, no synchronisation between the frames
+            got = [torch.cat([o['rgb'], o['alpha'][:, None], o['depth'][:, None]], 1) for o in outs]
+            if ref is None:
+                ref = got
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), chunks
+    finally:
+        net.cfg.overlap_chunks = 0
+        net.cfg.dedup_repeated_samples = True
+
+
 @pytest.mark.parametrize('n,kcols,ccols', [(1, 3, 3), (300, 3, 3), (70001, 68, 68), (5000, 4, 8), (257, 3, 3)])
 def test_repeat_heads(ops, n, kcols, ccols):
     """Run-length elimination of repeated rows against numpy: scan, head list, head count, head mask -- with and without a
