@@ -19,7 +19,18 @@ Key names and shapes are exactly the reference's, so the
 loads with ``strict=True`` into either implementation.  ``amplify=True`` gives a
 "trained-like" variant (O(1) hash features, visible non-rigid offsets and pose
 corrections, non-uniform visibility counts) that makes parity tests sensitive to
-every stage; it is not the benchmark checkpoint.
+every stage; it is not the benchmark checkpoint.  ``amplify='trained'`` (= 2) is the
+third recipe, shaped like what a loaded checkpoint holds after optimisation (run.py:26-37)
+rather than like either extreme: hash features of amplitude 0.05 with a low-frequency
+component (60 % a sine of the entry index with a period of 97 entries -- along x on the
+dense levels, where the index is the cell coordinate -- plus 40 % noise), a density head
+whose sigma spans roughly -15 ... +22 over the body (row 0 of geo_linear x 640, bias -28:
+the pre-activation sits at 0.02 ... 0.08 there) -- a density that rises by ~1e4 per metre
+like a learnt surface -- so that softplus(sigma) x step covers per-sample alphas from 0 to
+above 0.5 and rays end anywhere between transparent and opaque,
+centimetre-scale non-rigid offsets, milliradian pose corrections, non-uniform visibility
+counts and point offsets as in the amplified recipe.  It is the checkpoint the 1e-4 pixel
+gate is held on besides the random-init one (tests/test_hip_parity.py).
 """
 import math
 import zlib
@@ -77,7 +88,9 @@ def make_state_dict(point_base, bound, seed=0, amplify=False, total_bones=24,
                     cnl_width=256, cnl_depth=4, nr_width=128, nr_depth=6, nr_skips=(4,),
                     nr_embed=36, cond_size=69, pose_width=256, pose_depth=4,
                     embedding_size=256, volume_size=32):
-    """-> OrderedDict-compatible dict of CPU float32 tensors (offsets int32)."""
+    """-> OrderedDict-compatible dict of CPU float32 tensors (offsets int32).  amplify: False / True / 'trained' (0 / 1 / 2)."""
+    amplify = {'trained': 2, 'amplified': 1}.get(amplify, amplify)
+    amplify = int(amplify)
     sd = {}
     P = point_base.shape[0]
     sd['point_base'] = torch.as_tensor(np.asarray(point_base)).float().clone()
@@ -121,7 +134,13 @@ def make_state_dict(point_base, bound, seed=0, amplify=False, total_bones=24,
     # canonical MLP (occnerf_mlp.py:31-83)
     offsets, _ = grid_offsets(4, 16, 2.0, 16, 19, desired_resolution=2048 * bound)
     k = 'cnl_mlp.module.encoder.embeddings'
-    sd[k] = _uniform((int(offsets[-1]), 2), 1.0 if amplify else 1e-4, seed, k)
+    if amplify == 2:
+        n_emb = int(offsets[-1])
+        i = torch.arange(n_emb, dtype=torch.float64)[:, None]
+        smooth = torch.sin(i * (2.0 * math.pi / 97.0) + torch.tensor([[0.0, 1.3]], dtype=torch.float64)).float()
+        sd[k] = 0.05 * (0.6 * smooth + 0.4 * _uniform((n_emb, 2), 1.0, seed, k + '.trained'))
+    else:
+        sd[k] = _uniform((int(offsets[-1]), 2), 1.0 if amplify else 1e-4, seed, k)
     sd['cnl_mlp.module.encoder.offsets'] = torch.from_numpy(offsets.copy())
     dims = [(68, cnl_width)] + [(cnl_width, cnl_width)] * (cnl_depth - 1)
     _mlp(sd, 'cnl_mlp.module.pts_linears', dims, [_RELU_GAIN] * cnl_depth, seed)
@@ -138,6 +157,9 @@ def make_state_dict(point_base, bound, seed=0, amplify=False, total_bones=24,
         sd['point_counter'] = torch.where(seen, counts, torch.ones(P))
         sd['point_dist'] = _uniform((P, 1), 5e-3, seed, 'point_dist.amp')
         sd['cnl_mlp.module.geo_linear.0.bias'][0] = 1.0      # denser field
+    if amplify == 2:                                          # a density head with trained-like dynamic range
+        sd['cnl_mlp.module.geo_linear.0.weight'][0] *= 640.0
+        sd['cnl_mlp.module.geo_linear.0.bias'][0] = -28.0
     return sd
 
 

@@ -182,8 +182,44 @@ def check_inputs_against_reference(frame, img_size, pose):
         np.abs(pr - frame['motion_weights_priors']).max()
 
 
+def fragile_rays(xyz, mask, net, rel=2e-5):
+    """[n] bool: the ray holds a live sample (motion-weight sum > 0) whose result is discontinuous within `rel`: at any
+    of the 4 scales the 10th and 11th nearest support points are nearly equidistant (the neighbour SET would change), at
+    the finest scale the 3rd and 4th are (occnerf_mlp.py:160-166 projects onto the first three), or the float64 inside
+    vote (occnerf_mlp.py:152: more than 5 of the 10 dots negative) stands at 5 or 6 with a dot product at zero."""
+    n, S = mask.shape
+    base = net.point_base.detach().numpy().astype(np.float64)
+    normals = _np(net.point_norms).astype(np.float64)
+    sets = [np.arange(base.shape[0])] + [_np(f).astype(np.int64) for f in net.fps_index]
+    live = np.flatnonzero(mask.reshape(-1) > 0)
+    q = xyz.astype(np.float64)[live]
+    frag = np.zeros(live.size, bool)
+    for lvl, idx in enumerate(sets):
+        pts = base[idx]
+        for lo in range(0, live.size, 2048):
+            d = np.linalg.norm(q[lo:lo + 2048, None, :] - pts[None], axis=-1)
+            part = np.argpartition(d, 11, axis=1)[:, :12]
+            ds = np.take_along_axis(d, part, 1)
+            o = np.argsort(ds, axis=1)
+            ds, part = np.take_along_axis(ds, o, 1), np.take_along_axis(part, o, 1)
+            gap = lambda j: (ds[:, j + 1] - ds[:, j]) / np.maximum(ds[:, j + 1], 1e-30)          # noqa: E731
+            f = gap(9) < rel
+            if lvl == 0:
+                f |= gap(2) < rel
+                nb = idx[part[:, :10]]
+                dirs = q[lo:lo + 2048, None, :] - base[nb]
+                dots = (dirs * normals[nb]).sum(-1)
+                cnt = (dots < 0).sum(1)
+                near0 = (np.abs(dots) < 1e-6 * np.linalg.norm(dirs, axis=-1) * np.linalg.norm(normals[nb], axis=-1)).any(1)
+                f |= near0 & ((cnt == 5) | (cnt == 6))
+            frag[lo:lo + 2048] |= f
+    bad = np.zeros(n * S, bool)
+    bad[live[frag]] = True
+    return bad.reshape(n, S).any(1)
+
+
 def run_case(name, img_size, S, amplify, pose=None, orbit_frame=0, non_rigid=False, seed=0,
-             keep_rays=None):
+             keep_rays=None, tie_free=False):
     print(f'== {name}: {img_size}x{img_size}, S={S}, amplify={amplify}, non_rigid={non_rigid}')
     cfg.N_samples = S
     cfg.perturb = 0.
@@ -192,24 +228,42 @@ def run_case(name, img_size, S, amplify, pose=None, orbit_frame=0, non_rigid=Fal
     pose72 = np.zeros(72, 'float32') if pose is None else pose
     frame = synth.make_frame(img_size=img_size, pose72=pose72, orbit_frame=orbit_frame)
     check_inputs_against_reference(frame, img_size, pose72)
-    if keep_rays is not None:                       # thin the ray set, keep a spread
-        R = frame['rays'].shape[1]
-        sel = np.linspace(0, R - 1, keep_rays).astype(np.int64)
-        frame['rays'] = frame['rays'][:, sel]
-        frame['near'], frame['far'] = frame['near'][sel], frame['far'][sel]
-        frame['ray_select'] = sel
-
-    net, sd = build_reference_network(seed, amplify)
-    net.eval()
-    rec = Recorder()
-    restore = instrument(net, rec)
     tkeys = ['rays', 'near', 'far', 'bgcolor', 'dst_Rs', 'dst_Ts', 'cnl_gtfms',
              'motion_weights_priors', 'cnl_bbox_min_xyz', 'cnl_bbox_max_xyz',
              'cnl_bbox_scale_xyz', 'dst_posevec']
-    data = {k: torch.from_numpy(np.ascontiguousarray(frame[k])) for k in tkeys}
-    with torch.no_grad():
-        out = net(**data, iter_val=cfg.eval_iter)
-    restore()
+    full = {k: frame[k] for k in ('rays', 'near', 'far')}
+
+    def reference_pass(sel):
+        if sel is not None:
+            frame['rays'] = full['rays'][:, sel]
+            frame['near'], frame['far'] = full['near'][sel], full['far'][sel]
+            frame['ray_select'] = sel
+        net, sd = build_reference_network(seed, amplify)
+        net.eval()
+        rec = Recorder()
+        restore = instrument(net, rec)
+        data = {k: torch.from_numpy(np.ascontiguousarray(frame[k])) for k in tkeys}
+        with torch.no_grad():
+            out = net(**data, iter_val=cfg.eval_iter)
+        restore()
+        return net, sd, rec, out
+
+    sel = None
+    if keep_rays is not None:                       # thin the ray set, keep a spread
+        R = full['rays'].shape[1]
+        sel = np.linspace(0, R - 1, keep_rays + (keep_rays // 4 if tie_free else 0)).astype(np.int64)
+    net, sd, rec, out = reference_pass(sel)
+    if tie_free:
+        # a neighbour set is a discontinuous function of the sample position.  A fixture that is to be
+        # held to 1e-4 on a non-trivial field must not contain samples that sit on such a discontinuity (the reference on
+        # other hardware would flip them too): rays with a fragile live sample are dropped and the reference runs again on
+        # the remaining ones (rays are independent: their results do not change).
+        bad = fragile_rays(rec.d['cnl.xyz'], rec.d['comp.mask'].reshape(len(sel), -1), net)
+        print(f'   tie-free fixture: {int(bad.sum())} of {len(sel)} candidate rays hold a live sample within 2e-5 (relative) of a '
+              'neighbour-set / inside-vote discontinuity: dropped')
+        sel = sel[~bad][:keep_rays]
+        net, sd, rec, out = reference_pass(sel)
+        assert not fragile_rays(rec.d['cnl.xyz'], rec.d['comp.mask'].reshape(len(sel), -1), net).any()
 
     g = {'meta.img_size': img_size, 'meta.S': S, 'meta.amplify': int(amplify),
          'meta.non_rigid': int(non_rigid), 'meta.seed': seed, 'meta.bound': float(net.bound),
@@ -390,5 +444,10 @@ if __name__ == '__main__':
         run_train_case('train_ri_s32', amplify=False)
     if 'all' in which or 'image' in which:
         run_image_case('tpose_ri_image32', img_size=32, S=32)
+    if 'all' in which or 'trained' in which:      # the trained-like checkpoint (checkpoint.py, amplify=2) at the 1e-4 gate
+        run_case('freeview_trained_s32', img_size=32, S=32, amplify=2, pose=synth.seeded_pose(1), orbit_frame=28,
+                 non_rigid=True, keep_rays=160, tie_free=True)
+        run_case('freeview_trained_s128', img_size=32, S=128, amplify=2, pose=synth.seeded_pose(3), orbit_frame=61,
+                 non_rigid=True, keep_rays=64, tie_free=True)
     if 'all' in which or 'tposeamp' in which:
         run_case('tpose_amp_s32', img_size=32, S=32, amplify=True, keep_rays=160)

@@ -13,7 +13,7 @@ CASES = util.GOLDEN_CASES
 @pytest.fixture(scope='module', params=CASES)
 def case(request):
     g = util.load_golden(request.param)
-    ctx = util.model_context(int(g['meta.seed']), bool(g['meta.amplify']))
+    ctx = util.model_context(int(g['meta.seed']), util.level(g))
     return g, ctx
 
 
@@ -98,7 +98,7 @@ def test_canonical_mlp(case, oracle):
     kb, dist = oracle.point_sdf(ctx['point_cloud'], ctx['point_base'], ctx['normals'])
     table = oracle.point_table(kb, dist, ctx['point_cloud'], ctx['bound'], ctx['embeddings'],
                                ctx['offsets'], ctx['S'], ctx['H'])
-    tol = 2e-3 if g['meta.amplify'] else 1e-7     # 1-ulp input change x O(1) fine-level features
+    tol = util.pick(g, 1e-7, 2e-3, 3e-4)     # 1-ulp input change x O(1) (amplified) / 0.05 (trained-like) fine-level features
     assert np.abs(table[:, :32] - g['enc_point.out']).max() <= tol
     Wg, Bg, Wc, Bc = util.canonical_mlp_params(ctx['sd'])
     raw, mlp_in = oracle.canonical_mlp(g['cnl.xyz'], g['cnl.knn_idxs'].astype(np.int32),
@@ -112,11 +112,12 @@ def test_canonical_mlp(case, oracle):
     # rgb logits, sigma.  With O(1) hash features (amplify) a 1-ulp difference in the encoder
     # input moves finest-level features by ~3e-4 (scale 4.4e3 cells x 6e-8); that conditioning
     # is the reference's own, so the tight check is done on reference-fed inputs below.
-    assert np.abs(raw[:, :4] - want[:, :4]).max() <= (5e-4 if g['meta.amplify'] else 2e-5)
+    assert np.abs(raw[:, :4] - want[:, :4]).max() <= util.pick(g, 2e-5, 5e-4, 2e-2)
     x = mlp_in.copy()
     x[:, 36:] = g['enc_sample.out']
-    assert np.abs(_mlp_f64(x, Wg, Bg, Wc, Bc) - want[:, :4]).max() <= (2e-4 if g['meta.amplify'] else 2e-5)
-    assert np.abs(_mlp_f64(mlp_in, Wg, Bg, Wc, Bc) - raw[:, :4]).max() <= 1e-5
+    assert np.abs(_mlp_f64(x, Wg, Bg, Wc, Bc) - want[:, :4]).max() <= util.pick(g, 2e-5, 2e-4, 5e-3)
+    # (trained-like: sigma = 640 x a 256-term dot product - 28, |sigma| up to 30: fp32 summation noise scales with it)
+    assert np.abs(_mlp_f64(mlp_in, Wg, Bg, Wc, Bc) - raw[:, :4]).max() <= util.pick(g, 1e-5, 1e-5, 5e-4)
 
 
 def _mlp_f64(x, Wg, Bg, Wc, Bc):
@@ -148,7 +149,7 @@ def test_composite(case, oracle):
     assert np.abs(acc - g['comp.acc']).max() <= 2e-6
     assert np.abs(dep - g['comp.depth']).max() <= 1e-5
     assert np.abs(w - g['comp.weights']).max() <= 2e-6
-    assert np.array_equal(tp, g['comp.term'].ravel())
+    util.assert_term_points(tp, g)
     assert np.array_equal(g['comp.rgb'], g['out.rgb'])
 
 
@@ -194,12 +195,12 @@ def test_make_golden_reproduces_committed_fixtures(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OCCNERF_GOLDEN_DIR=str(tmp_path))
     r = subprocess.run([sys.executable, os.path.join(root, 'oracle', 'ref_harness', 'make_golden.py'),
-                        'rays', 'tpose', 'movement', 'train'], env=env, cwd=str(tmp_path), capture_output=True, text=True,
+                        'rays', 'tpose', 'movement', 'train', 'trained'], env=env, cwd=str(tmp_path), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     made = sorted(os.listdir(tmp_path))
-    assert made == ['movement_amp_s32_f3.npz', 'movement_amp_s32_f9.npz', 'rays_cameras.npz', 'tpose_ri_s32.npz',
-                    'train_amp_s32.npz', 'train_ri_s32.npz']
+    assert made == ['freeview_trained_s128.npz', 'freeview_trained_s32.npz', 'movement_amp_s32_f3.npz',
+                    'movement_amp_s32_f9.npz', 'rays_cameras.npz', 'tpose_ri_s32.npz', 'train_amp_s32.npz', 'train_ri_s32.npz']
     for f in made:
         a, b = np.load(tmp_path / f), np.load(os.path.join(util.GOLDEN_DIR, f))
         assert sorted(a.files) == sorted(b.files), f
