@@ -174,6 +174,11 @@ int occnerf_nonrigid_pack_bf16(const float *const *h_W, void *packed_bf16, void 
 int occnerf_nonrigid_bf16x3(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
                             const float *W0, const float *b0, float *packed, const void *packed_bf16,
                             float *xyz_out, void *stream);
+/* In place on the listed samples only (as occnerf_nonrigid_rows for the fp32 kernel): xyz[rows[i]] += offset for
+ * i < *n_dev (device-side count, <= N_max). */
+int occnerf_nonrigid_bf16x3_rows(float *xyz, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
+                                 const float *cond, const float *h_hann, const float *W0, const float *b0,
+                                 float *packed, const void *packed_bf16, void *stream);
 
 /* Multi-scale exact kNN (k = 10, up to 4 point sets).  Replaces the pykeops
  * Kmin_argKmin reduction of knn.py:77-85 and the index bookkeeping of network.py:235-255.
@@ -367,6 +372,12 @@ int occnerf_canonical_mlp_pack_bf16(const float *const *h_W, void *packed_bf16, 
 int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const float *packed,
                                  const void *packed_bf16, float *raw, int32_t variant,
                                  void *stream);
+/* The renderer's call (as occnerf_canonical_mlp_rows / _counted for the fp32 kernel): the entry count is read from
+ * device memory (*n_dev <= N_max; the launch is sized for N_max), entry n's input row is mlp_in[in_rows[n]]
+ * (in_rows nullable: row n), its result goes to raw[n]. */
+int occnerf_canonical_mlp_bf16x3_rows(const float *mlp_in, const int32_t *in_rows, int64_t N_max,
+                                      const int32_t *n_dev, const float *packed, const void *packed_bf16,
+                                      float *raw, int32_t variant, void *stream);
 
 /* Alpha compositing, network.py:320-348.  raw[n,S,5], mask[n*S], z_vals[n,S],
  * rays[n,8] (direction at floats 3..5), h_bgcolor[3] host, 0..255.

@@ -41,6 +41,7 @@ SIGNATURES = {
     'occnerf_nonrigid_packed_bf16_bytes': (_i64, []),
     'occnerf_nonrigid_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_nonrigid_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_nonrigid_bf16x3_rows': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_msknn': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     'occnerf_msknn_clustered': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
                                            _vp, _vp, _vp, _vp, _vp]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     'occnerf_canonical_mlp_packed_bf16_bytes': (_i64, []),
     'occnerf_canonical_mlp_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_canonical_mlp_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    'occnerf_canonical_mlp_bf16x3_rows': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
     'occnerf_composite': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_linear_pack': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'occnerf_linear_forward': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32,

@@ -396,14 +396,17 @@ __device__ __forceinline__ float dot_row_relu(const f32x16 (&acc)[kOB], const fl
 }
 
 __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_kernel(
-    const float *__restrict__ mlp_in, int64_t N, const float *__restrict__ pk,
+    const float *__restrict__ mlp_in, const int32_t *__restrict__ in_rows /*nullable: input row of entry n*/, int64_t N_max,
+    const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/, const float *__restrict__ pk,
     const bf16x8 *__restrict__ pkh, float *__restrict__ raw) {
+    const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (tile * 32 >= N) return;
     const int64_t n = tile * 32 + j;
-    const int64_t nsrc = n < N ? n : N - 1;
+    const int64_t nsrc0 = n < N ? n : N - 1;
+    const int64_t nsrc = in_rows ? (int64_t)in_rows[nsrc0] : nsrc0;
 
     // layer-0 operands: slot t of half h carries input feature h*34 + t (t < 34), 5 k-steps
     SplitB bx[kS_L0Geo];
@@ -536,8 +539,11 @@ __device__ __forceinline__ void lds_bias(f32x16 (&acc)[OB], const float *aux, in
 }
 
 __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
-    const float *__restrict__ mlp_in, int64_t N, const float *__restrict__ pk,
+    const float *__restrict__ mlp_in, const int32_t *__restrict__ in_rows /*nullable: input row of entry n*/, int64_t N_max,
+    const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/, const float *__restrict__ pk,
     const bf16x8 *__restrict__ pkh, float *__restrict__ raw) {
+    const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
+    if ((int64_t)blockIdx.x * 128 >= N) return;      // launches are sized for the worst case; uniform per workgroup
     // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read)
     __shared__ __attribute__((aligned(16))) bf16x8 smem[kRingSlots * kChunkUnits + Aux::kTotal / 4];
     bf16x8 *ring = smem;
@@ -548,7 +554,8 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
     const int j = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     const int64_t n = tile * 32 + j;
-    const int64_t nsrc = n < N ? n : N - 1;      // whole workgroup stays alive for the barriers
+    const int64_t nsrc0 = n < N ? n : N - 1;      // whole workgroup stays alive for the barriers
+    const int64_t nsrc = in_rows ? (int64_t)in_rows[nsrc0] : nsrc0;
 
     // ---- side data -> LDS, inputs -> registers (ordinary loads, before any DMA is in flight) ----
     auto copy = [&](int dst, int64_t src, int count) {
@@ -774,22 +781,35 @@ OCC_API int occnerf_canonical_mlp_pack_bf16(const float *const *h_W, void *packe
     return check_launch("canonical_mlp_pack_bf16");
 }
 
-OCC_API int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const float *packed,
-                                         const void *packed_bf16, float *raw, int32_t variant,
-                                         void *stream) {
+static int mlp_bf16x3_launch(const float *mlp_in, const int32_t *in_rows, int64_t N_max, const int32_t *n_dev,
+                             const float *packed, const void *packed_bf16, float *raw, int32_t variant, void *stream) {
     using namespace occ;
-    if (N <= 0) return 0;
-    OCC_REQUIRE(mlp_in && packed && packed_bf16 && raw, "canonical_mlp_bf16x3: null argument");
-    const int64_t blocks = (N + 127) / 128;
+    const int64_t blocks = (N_max + 127) / 128;
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_bf16x3: N too large");
     const bf16x8 *pkh = reinterpret_cast<const bf16x8 *>(packed_bf16);
     if (variant == 0)
         hipLaunchKernelGGL(canonical_mlp_bf16x3_lds_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                           as_stream(stream), mlp_in, N, packed, pkh, raw);
+                           as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
     else
         hipLaunchKernelGGL(canonical_mlp_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                           as_stream(stream), mlp_in, N, packed, pkh, raw);
+                           as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
     return check_launch("canonical_mlp_bf16x3");
+}
+
+OCC_API int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const float *packed,
+                                         const void *packed_bf16, float *raw, int32_t variant,
+                                         void *stream) {
+    if (N <= 0) return 0;
+    OCC_REQUIRE(mlp_in && packed && packed_bf16 && raw, "canonical_mlp_bf16x3: null argument");
+    return mlp_bf16x3_launch(mlp_in, nullptr, N, nullptr, packed, packed_bf16, raw, variant, stream);
+}
+
+OCC_API int occnerf_canonical_mlp_bf16x3_rows(const float *mlp_in, const int32_t *in_rows, int64_t N_max,
+                                              const int32_t *n_dev, const float *packed, const void *packed_bf16,
+                                              float *raw, int32_t variant, void *stream) {
+    if (N_max <= 0) return 0;
+    OCC_REQUIRE(mlp_in && n_dev && packed && packed_bf16 && raw, "canonical_mlp_bf16x3_rows: null argument");
+    return mlp_bf16x3_launch(mlp_in, in_rows, N_max, n_dev, packed, packed_bf16, raw, variant, stream);
 }
 
 OCC_API int occnerf_canonical_mlp(const float *mlp_in, int64_t N, const float *packed, float *raw,

@@ -292,7 +292,9 @@ __device__ __forceinline__ void nr_glds16(const void *gbase, unsigned lane_off, 
 
 #define NR_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-__global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N,
+__global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N_max,
+                                                                 const int32_t *__restrict__ rows /*nullable: sample of entry n*/,
+                                                                 const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/,
                                                                  const float *__restrict__ pk,
                                                                  const bf16x8 *__restrict__ pkh, NrParams prm,
                                                                  float *xyz_out) {
@@ -302,8 +304,11 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xy
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
+    const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
+    if ((int64_t)blockIdx.x * 128 >= N) return;      // launches are sized for the worst case; uniform per workgroup
     const int64_t n = ((int64_t)blockIdx.x * 4 + wave) * 32 + j;
-    const int64_t nsrc = n < N ? n : N - 1;
+    const int64_t nsrc0 = n < N ? n : N - 1;
+    const int64_t nsrc = rows ? (int64_t)rows[nsrc0] : nsrc0;      // (with a row list the offsets are written back to the listed rows)
 
     auto copy = [&](int dst, int64_t src, int count) {
         for (int i = threadIdx.x; i < count; i += 256) aux[dst + i] = pk[src + i];
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xy
     }
     if (h == 0 && n < N) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) xyz_out[n * 3 + c] = __fadd_rn(p[c], off[c]);
+        for (int c = 0; c < 3; c++) xyz_out[nsrc * 3 + c] = __fadd_rn(p[c], off[c]);
     }
 #undef NR_STEP
 #undef NR_BIAS
@@ -511,9 +516,27 @@ OCC_API int occnerf_nonrigid_bf16x3(const float *xyz_in, int64_t N, const float 
     for (int i = 0; i < 6; i++) prm.hann[i] = h_hann[i];
     const int64_t blocks = (N + 127) / 128;
     OCC_REQUIRE(blocks < (1ll << 31), "nonrigid_bf16x3: N too large");
-    hipLaunchKernelGGL(nonrigid_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N, packed,
+    hipLaunchKernelGGL(nonrigid_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N, nullptr, nullptr, packed,
                        reinterpret_cast<const bf16x8 *>(packed_bf16), prm, xyz_out);
     return check_launch("nonrigid_bf16x3");
+}
+
+OCC_API int occnerf_nonrigid_bf16x3_rows(float *xyz, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
+                                         const float *cond, const float *h_hann, const float *W0, const float *b0,
+                                         float *packed, const void *packed_bf16, void *stream) {
+    using namespace occ;
+    if (N_max <= 0) return 0;
+    OCC_REQUIRE(xyz && rows && n_dev && cond && h_hann && W0 && b0 && packed && packed_bf16,
+                "nonrigid_bf16x3_rows: null argument");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(nr_fold_bias_kernel, dim3(1), dim3(128), 0, st, W0, b0, cond, packed + NrBlob::kL0B);
+    NrParams prm;
+    for (int i = 0; i < 6; i++) prm.hann[i] = h_hann[i];
+    const int64_t blocks = (N_max + 127) / 128;
+    OCC_REQUIRE(blocks < (1ll << 31), "nonrigid_bf16x3_rows: N too large");
+    hipLaunchKernelGGL(nonrigid_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz, N_max, rows, n_dev, packed,
+                       reinterpret_cast<const bf16x8 *>(packed_bf16), prm, xyz);
+    return check_launch("nonrigid_bf16x3_rows");
 }
 
 OCC_API int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,

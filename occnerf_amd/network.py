@@ -252,7 +252,10 @@ class Network(nn.Module):
         scan_a = scan_b = mrows = mcount = None
         frows, fcount, kmask = rows, count, mask
         if not cfg.ignore_non_rigid_motions:
-            ops.nonrigid_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
+            if pk['nr_bf16'] is not None:      # opt-in split-bf16 MFMA path (cfg.mlp_precision): same list, same count
+                ops.nonrigid_bf16x3_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'])
+            else:
+                ops.nonrigid_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
         if dedup:       # (the positions before the offset differ in their last bits; after it they coincide)
             scan_a, frows, fcount, kmask = ops.repeat_heads(xyz, 3, count, rows=rows,
                                                             want_mask=not cfg.get('knn_query_list', True))
@@ -278,20 +281,26 @@ class Network(nn.Module):
             self.last_head_counts = (fcount, mcount)
         return {'dedup': dedup, 'rays8': rays8, 'z': z, 'mask': mask, 'rows': rows, 'count': count, 'mlp_in': mlp_in,
                 'raw_c': raw_c, 'scan_a': scan_a, 'scan_b': scan_b, 'mrows': mrows, 'mcount': mcount, 'cnl': pk['cnl'],
-                'N': xyz.shape[0]}
+                'cnl_bf16': pk['cnl_bf16'], 'N': xyz.shape[0]}
 
     @staticmethod
     def _stage_mlp_composite(st, bgcolor, out, out_rows):
         """Second half of a pass (the matrix-pipe kernel + the per-ray scan): canonical MLP on the feature rows, results back
         to their samples, alpha compositing into the frame's rows."""
         dev, N = st['mlp_in'].device, st['N']
+
+        def mlp(raw_out, count, in_rows=None):
+            if st['cnl_bf16'] is not None:          # opt-in split-bf16 MFMA path (cfg.mlp_precision)
+                ops.canonical_mlp_bf16x3(st['mlp_in'], st['cnl'], st['cnl_bf16'], raw_out, count=count, in_rows=in_rows)
+            else:
+                ops.canonical_mlp(st['mlp_in'], st['cnl'], raw_out, count=count, in_rows=in_rows)
         if st['dedup']:
             raw_h = torch.empty(st['mlp_in'].shape[0], 5, device=dev)
-            ops.canonical_mlp(st['mlp_in'], st['cnl'], raw_h, count=st['mcount'], in_rows=st['mrows'])
+            mlp(raw_h, st['mcount'], st['mrows'])
             raw = ops.scatter_raw_heads(raw_h, st['raw_c'], st['rows'], st['count'], st['scan_a'], st['scan_b'],
                                         torch.zeros(N, 5, device=dev))
         else:
-            ops.canonical_mlp(st['mlp_in'], st['cnl'], st['raw_c'], count=st['count'])
+            mlp(st['raw_c'], st['count'])
             raw = ops.scatter_raw(st['raw_c'], st['rows'], st['count'], torch.zeros(N, 5, device=dev))
         st['mlp_in'] = None
         return ops.composite(raw, st['mask'], st['z'], st['rays8'], bgcolor, out=out, out_rows=out_rows)[:3]
@@ -347,51 +356,31 @@ class Network(nn.Module):
         # are dropped here -- a quarter of the samples of the benchmark frame -- and the pixel values are
         # bit-identical to evaluating them (cfg.skip_empty_samples=False; tested).
         N = xyz.shape[0]
-        fp32 = pk['cnl_bf16'] is None and pk['nr_bf16'] is None
-        if cfg.get('skip_empty_samples', True) and cfg.get('knn_culling', True) and fp32:
+        if cfg.get('skip_empty_samples', True) and cfg.get('knn_culling', True):
+            # (fp32 and the opt-in split-bf16 kernels alike: list and count of the live samples on the device, no host sync)
             st = self._stage_features(rays8, z, xyz, mask, pk, cond, hann, table, pack)
             return self._stage_mlp_composite(st, bgcolor, out, out_rows)
 
-        # split-bf16 kernels (opt-in) take the list through the host: one nonzero = one sync
-        rows = None
-        if cfg.get('skip_empty_samples', True) and cfg.get('knn_culling', True):
-            rows64 = torch.nonzero(mask).squeeze(1)
-            rows = None if rows64.numel() == N else rows64.int()
-        if rows is not None and rows.numel() == 0:
-            raw = torch.zeros(N, 5, device=xyz.device)
-            return ops.composite(raw, mask, z, rays8, bgcolor, out=out, out_rows=out_rows)[:3]
-
-        def nonrigid(x):
-            if pk['nr_bf16'] is not None:
-                return ops.nonrigid_bf16x3(x, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'], out=x)
-            return ops.nonrigid(x, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=x)
-
+        # every sample evaluated (cfg.skip_empty_samples off) and / or the brute-force neighbour search (cfg.knn_culling off)
         if not cfg.ignore_non_rigid_motions:
-            if rows is None:
-                xyz = nonrigid(xyz)
-            else:                                                # offsets only for the kept samples
-                xyz[rows64] = nonrigid(xyz[rows64])
+            if pk['nr_bf16'] is not None:
+                ops.nonrigid_bf16x3(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'], out=xyz)
+            else:
+                ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
         if cfg.get('knn_culling', True):     # same results, ~5x fewer distance evaluations
-            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'],
-                                      mask=mask if rows is not None else None)
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'])
         else:
             knn = ops.msknn(xyz, ctx['points'], ctx['index_map'], ctx['scale_begin'], ctx['seed'])
-        mlp_in, raw_c, _ = ops.sample_features(
+        mlp_in, raw, _ = ops.sample_features(
             xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
-            enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution,
-            rows=rows, pack=pack)
+            enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution, pack=pack)
         del knn
         if pk['cnl_bf16'] is not None:          # opt-in split-bf16 MFMA path (cfg.mlp_precision)
-            ops.canonical_mlp_bf16x3(mlp_in, pk['cnl'], pk['cnl_bf16'], raw_c)
+            ops.canonical_mlp_bf16x3(mlp_in, pk['cnl'], pk['cnl_bf16'], raw)
         else:
-            ops.canonical_mlp(mlp_in, pk['cnl'], raw_c)
+            ops.canonical_mlp(mlp_in, pk['cnl'], raw)
         del mlp_in
-        if raw_c.shape[0] == N:
-            raw = raw_c
-        else:
-            raw = torch.zeros(N, 5, device=xyz.device)
-            raw[rows64] = raw_c
         return ops.composite(raw, mask, z, rays8, bgcolor, out=out, out_rows=out_rows)[:3]
 
     @staticmethod
@@ -495,7 +484,7 @@ class Network(nn.Module):
                 rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 28)) // S)
                 n_over = int(cfg.get('overlap_chunks', 0))
                 overlap = (n_over > 1 and R >= n_over * 1024 and cfg.get('skip_empty_samples', True) and
-                           cfg.get('knn_culling', True) and cfg.get('mlp_precision', 'fp32') != 'bf16x3')
+                           cfg.get('knn_culling', True))
                 if overlap:      # chunks of whole 256-ray blocks (four kNN tiles), two streams (see _render_overlapped)
                     per = min(rays_per_pass, -(-R // (n_over * 256)) * 256)
                     chunks = [(rays8[i:i + per], None if order is None else order[i:i + per],

@@ -376,6 +376,18 @@ def nonrigid_bf16x3(xyz, cond, hann, W0, b0, packed, packed_bf16, out=None):
     return out
 
 
+def nonrigid_bf16x3_rows(xyz, rows, count, cond, hann, W0, b0, packed, packed_bf16):
+    """In place on the listed samples (the split-bf16 counterpart of nonrigid_rows): xyz[rows[i]] += offset, i < count[0]."""
+    _kh, ph = _host_f32(hann, 6)
+    with _guard(xyz):
+        rc = _lib.lib().occnerf_nonrigid_bf16x3_rows(
+            _chk(xyz, torch.float32, 'xyz'), rows.shape[0], _chk(rows, torch.int32, 'rows'), _chk(count, torch.int32, 'count'),
+            _chk(cond, torch.float32, 'cond'), ph, _chk(W0, torch.float32, 'W0'), _chk(b0, torch.float32, 'b0'),
+            _chk(packed, torch.float32, 'packed'), _chk(packed_bf16, torch.bfloat16, 'packed_bf16'), _stream(xyz))
+    _lib.check(rc, 'nonrigid_bf16x3_rows')
+    return xyz
+
+
 def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
     N = xyz.shape[0]
     nscale = len(scale_begin) - 1
@@ -568,12 +580,23 @@ def canonical_mlp_pack_bf16(weights):
     return packed
 
 
-def canonical_mlp_bf16x3(mlp_in, packed, packed_bf16, raw, variant=0):
+def canonical_mlp_bf16x3(mlp_in, packed, packed_bf16, raw, variant=0, count=None, in_rows=None):
+    """count (int32[1] on the device): entries to evaluate, read by the kernel (the launch covers the worst case);
+    in_rows (int32, optional): entry n takes input row in_rows[n]; results are compact (raw[n])."""
     with _guard(mlp_in):
-        rc = _lib.lib().occnerf_canonical_mlp_bf16x3(
-            _chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0], _chk(packed, torch.float32, 'packed'),
-            _chk(packed_bf16, torch.bfloat16, 'packed_bf16'), _chk(raw, torch.float32, 'raw'),
-            int(variant), _stream(mlp_in))
+        if count is None:
+            assert in_rows is None
+            rc = _lib.lib().occnerf_canonical_mlp_bf16x3(
+                _chk(mlp_in, torch.float32, 'mlp_in'), mlp_in.shape[0], _chk(packed, torch.float32, 'packed'),
+                _chk(packed_bf16, torch.bfloat16, 'packed_bf16'), _chk(raw, torch.float32, 'raw'),
+                int(variant), _stream(mlp_in))
+        else:
+            n_max = mlp_in.shape[0] if in_rows is None else in_rows.shape[0]
+            rc = _lib.lib().occnerf_canonical_mlp_bf16x3_rows(
+                _chk(mlp_in, torch.float32, 'mlp_in'), _opt(in_rows, torch.int32, 'in_rows'), n_max,
+                _chk(count, torch.int32, 'count'), _chk(packed, torch.float32, 'packed'),
+                _chk(packed_bf16, torch.bfloat16, 'packed_bf16'), _chk(raw, torch.float32, 'raw'), int(variant),
+                _stream(mlp_in))
     _lib.check(rc, 'canonical_mlp_bf16x3')
     return raw
 

@@ -21,8 +21,18 @@
  *     calls as GPU code: the torch-ngp grid encoder (gridencoder/src/gridencoder.cu,
  *     CUDA only, cannot execute here) and pykeops' Kmin_argKmin (pykeops is not
  *     vendored; requirements.txt:11, unpinned).  Both are restated from source /
- *     published semantics and cross-checked against an independent numpy/float64
- *     implementation in the harness.
+ *     published semantics.  What IS cross-checked, in the CPU suite: the encoder against
+ *     a second, independent numpy restatement written from the CUDA source (uint32
+ *     wrap-around, fp32 steps, exact fma emulation) bit for bit on the golden inputs
+ *     and on five other template instantiations, with every assumed nvcc contraction
+ *     and exp2f's last ulp flipped and the number of outputs that move put on record
+ *     (tests/test_encoder_restatement.py); the kNN against exact integer arithmetic on
+ *     an adversarial tie model -- duplicated support points, queries equidistant to up
+ *     to 24 points at all four scales, lowest row first (tests/util.py::knn_tie_model,
+ *     tests/test_oracle_golden.py::test_msknn_tie_suite_oracle) -- and against a float64
+ *     brute force on golden queries.  What stays unverifiable without the CUDA binary:
+ *     which a*b+c nvcc fuses, CUDA's exp2f to the ulp, and KeOps' tie order beyond its
+ *     documented rule.
  */
 #include <math.h>
 #include <stdint.h>

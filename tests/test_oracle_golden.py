@@ -76,6 +76,19 @@ def test_msknn_bit_exact(case, oracle):
     assert util.knn_mismatch_is_tie(xyz[:256], ctx['point_base'], got[:256, 0], ref)
 
 
+def test_msknn_tie_suite_oracle(oracle):
+    """the kNN restatement on an adversarial tie model (tests/util.py::knn_tie_model: exact duplicates,
+    queries equidistant to 2 ... 24 support points at every scale, the k = 10 cut inside a tie group) against the documented
+    KeOps rule -- lowest row of the scale's block first -- evaluated in exact integer arithmetic."""
+    for seed in (0, 1, 2):
+        base, sets, q, want = util.knn_tie_model(seed=seed)
+        got = oracle.msknn(q, base, sets[1:], k=10)
+        assert np.array_equal(got, want), seed
+    # k = 3 single-scale search (network.py:265, the per-point block) on the same model: ties to the lower row as well
+    base, sets, q, want = util.knn_tie_model(seed=3)
+    assert np.array_equal(oracle.knn(q, base, 3), want[:, 0, :3])
+
+
 def test_point_sdf(case, oracle):
     g, ctx = case
     kb, dist = oracle.point_sdf(ctx['point_cloud'], ctx['point_base'], ctx['normals'])

@@ -61,3 +61,50 @@ def assert_term_points(tp_got, g):
         for r in bad:
             assert abs(a64[r, tp_h[r]] - a64[r, tp_r[r]]) <= 1e-6 * a64[r].max() or a64[r].max() < 6e-8, (r, tp_h[r], tp_r[r])
         assert bad.size <= max(1, n // 50)
+
+
+def knn_tie_model(n_rays=64, S=8, seed=0):
+    """An adversarial TIE model for the multi-scale kNN (row a10): support points on a lattice of pitch 1/8 (every coordinate,
+    difference, square and sum of squares is exact in fp32, so equal squared distances are bit-equal distances after the
+    correctly rounded sqrt), 40 of them stored twice (exact duplicates in different rows), three coarser scales that are
+    shuffled subsets (a row's place in its scale is not its base index); queries on lattice points (distance 0 to a point AND
+    its duplicate), cell centres (8 equidistant corners, then 24), face centres, edge midpoints and far points on the axes --
+    at every scale the k = 10 cut falls inside a group of equidistant points.  Expected result by the documented KeOps rule
+    (knn.py:77-85 `Kmin_argKmin`: k smallest, ascending, the LOWEST ROW of the scale's block first among equals), computed
+    with exact integer arithmetic.  -> base[P,3] f32, sets (list of 4 index arrays), queries[n_rays*S,3] f32, want[N,4,10]."""
+    rng = np.random.RandomState(seed)
+    g = np.arange(6)
+    lat = np.stack(np.meshgrid(g, g, g, indexing='ij'), -1).reshape(-1, 3)                  # integer lattice coordinates
+    lat = lat[rng.permutation(len(lat))]
+    pts_i = np.concatenate([lat, lat[:40]])                                                   # 256 rows, 40 exact duplicates
+    P = len(pts_i)
+    s1 = rng.permutation(np.arange(0, P, 2))
+    s2 = rng.permutation(s1[::2])
+    s3 = rng.permutation(s2[::2])
+    sets = [np.arange(P), s1, s2, s3]
+    N = n_rays * S
+    kinds = rng.randint(0, 5, N)
+    q2 = np.empty((N, 3), np.int64)                                                           # queries in HALF lattice units
+    cell = rng.randint(0, 5, (N, 3))
+    q2[kinds == 0] = 2 * rng.randint(0, 6, (int((kinds == 0).sum()), 3))                      # on a lattice point
+    q2[kinds == 1] = 2 * cell[kinds == 1] + 1                                                 # cell centre
+    f = 2 * cell[kinds == 2] + 1
+    f[np.arange(len(f)), rng.randint(0, 3, len(f))] -= 1                                      # face centre
+    q2[kinds == 2] = f
+    e = 2 * cell[kinds == 3]
+    e[np.arange(len(e)), rng.randint(0, 3, len(e))] += 1                                      # edge midpoint
+    q2[kinds == 3] = e
+    far = np.full((int((kinds == 4).sum()), 3), 5)                                            # far away on an axis through the middle
+    far[np.arange(len(far)), rng.randint(0, 3, len(far))] = rng.choice([-40, 60], len(far))
+    q2[kinds == 4] = far
+    want = np.empty((N, 4, 10), np.int32)
+    for s, idx in enumerate(sets):
+        d2 = ((q2[:, None, :] - 2 * pts_i[idx][None, :, :]) ** 2).sum(-1)                     # exact integers
+        order = np.lexsort((np.broadcast_to(np.arange(len(idx)), d2.shape), d2), axis=1)[:, :10]
+        want[:, s] = idx[order]
+        # the cut really crosses a tie group somewhere at this scale
+        srt = np.sort(d2, axis=1)
+        assert (srt[:, 9] == srt[:, 10]).any(), s
+    base = (pts_i / 8.0).astype(np.float32)
+    queries = (q2 / 16.0).astype(np.float32)
+    return base, sets, queries, want
