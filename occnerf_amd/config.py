@@ -90,7 +90,9 @@ _DEFAULTS = {
     # build-specific keys
     'smpl_model': 'auto',            # 'auto' | 'synthetic' | directory holding the SMPL pickles
     # samples resident per pipeline pass (~470 B each): 2^28 keeps a whole 1024^2 x 192 frame (141 M samples, 63 GiB peak of the
-    # 288 GB) in ONE pass; larger frames run in several, bit-identically
+    # 288 GB) in ONE pass; larger frames run in several, bit-identically.  The renderer additionally caps a pass at half of
+    # the device memory that is free when the frame starts (Network.forward: min(this, free / 2 / 470 B)), so a smaller GPU
+    # or ranks sharing one device split a large frame instead of running out of memory.
     'max_samples_per_pass': 1 << 28,
     # 'fp32': exact fp32 MFMA (default, the parity/benchmark path); 'bf16x3': split-bf16 MFMA,
     # ~3x faster MLP, raw logits within ~1e-5 of fp32

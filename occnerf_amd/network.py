@@ -481,7 +481,10 @@ class Network(nn.Module):
                 rays8 = ops.pack_rays(rays_f, f32(near).reshape(-1), f32(far).reshape(-1), order)
                 out = (torch.empty(R, 3, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev))
                 # all rays of the frame in as few passes as memory allows
-                rays_per_pass = max(1, int(cfg.get('max_samples_per_pass', 1 << 28)) // S)
+                cap = int(cfg.get('max_samples_per_pass', 1 << 28))
+                if R * S > (1 << 26):      # (a frame of > 30 GB: ~470 B per resident sample, at most half of what is free)
+                    cap = min(cap, max(1 << 22, int(torch.cuda.mem_get_info(dev)[0] // 2 // 470)))
+                rays_per_pass = max(1, cap // S)
                 n_over = int(cfg.get('overlap_chunks', 0))
                 overlap = (n_over > 1 and R >= n_over * 1024 and cfg.get('skip_empty_samples', True) and
                            cfg.get('knn_culling', True))

@@ -813,29 +813,28 @@ def test_full_size_properties(ops, oracle):
     net, ctx = build_network(0, False, S=128, non_rigid=True)
     frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
     data = frame_to_device(frame, DEV)
-    torch.set_grad_enabled(False)
-    out = net(**data, iter_val=1e7)
-    R = frame['rays'].shape[1]
-    assert out['rgb'].shape == (R, 3) and out['alpha'].shape == (R,)
-    rgb, acc = out['rgb'], out['alpha']
-    assert torch.isfinite(rgb).all() and torch.isfinite(out['depth']).all()
-    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
-    assert float(rgb.min()) >= -1e-6 and float(rgb.max()) <= 1.0 + 1e-5
-    # determinism: same frame twice -> identical bits
-    out2 = net(**data, iter_val=1e7)
-    assert torch.equal(out2['rgb'], rgb) and torch.equal(out2['depth'], out['depth'])
-    # ray sharding: rendering a slice of the rays gives the same pixels (no cross-ray coupling)
-    lo, hi = R // 3, R // 3 + 4097
-    part = dict(data)
-    part['rays'], part['near'], part['far'] = data['rays'][:, lo:hi].contiguous(), data['near'][lo:hi], data['far'][lo:hi]
-    outp = net(**part, iter_val=1e7)
-    assert torch.equal(outp['rgb'], rgb[lo:hi]) and torch.equal(outp['alpha'], acc[lo:hi])
-    # a random subset of rays against the full CPU oracle
-    sel = np.sort(np.random.RandomState(0).choice(R, 96, replace=False))
-    sub = dict(frame)
-    sub['rays'], sub['near'], sub['far'] = frame['rays'][:, sel], frame['near'][sel], frame['far'][sel]
-    want = stagewise_oracle_render(None, ctx, frame=sub, S=128, non_rigid=True)
-    torch.set_grad_enabled(True)
+    with torch.no_grad():      # (scoped: a failing assert must not leave later autograd tests in no-grad mode)
+        out = net(**data, iter_val=1e7)
+        R = frame['rays'].shape[1]
+        assert out['rgb'].shape == (R, 3) and out['alpha'].shape == (R,)
+        rgb, acc = out['rgb'], out['alpha']
+        assert torch.isfinite(rgb).all() and torch.isfinite(out['depth']).all()
+        assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+        assert float(rgb.min()) >= -1e-6 and float(rgb.max()) <= 1.0 + 1e-5
+        # determinism: same frame twice -> identical bits
+        out2 = net(**data, iter_val=1e7)
+        assert torch.equal(out2['rgb'], rgb) and torch.equal(out2['depth'], out['depth'])
+        # ray sharding: rendering a slice of the rays gives the same pixels (no cross-ray coupling)
+        lo, hi = R // 3, R // 3 + 4097
+        part = dict(data)
+        part['rays'], part['near'], part['far'] = data['rays'][:, lo:hi].contiguous(), data['near'][lo:hi], data['far'][lo:hi]
+        outp = net(**part, iter_val=1e7)
+        assert torch.equal(outp['rgb'], rgb[lo:hi]) and torch.equal(outp['alpha'], acc[lo:hi])
+        # a random subset of rays against the full CPU oracle
+        sel = np.sort(np.random.RandomState(0).choice(R, 96, replace=False))
+        sub = dict(frame)
+        sub['rays'], sub['near'], sub['far'] = frame['rays'][:, sel], frame['near'][sel], frame['far'][sel]
+        want = stagewise_oracle_render(None, ctx, frame=sub, S=128, non_rigid=True)
     for k in ('rgb', 'alpha', 'depth'):
         assert np.abs(out[k].cpu().numpy()[sel] - want[k]).max() <= 1e-4, k
 
