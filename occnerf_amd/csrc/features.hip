@@ -405,6 +405,12 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
     // 64 when every lane has its own line): the five (tail, count) gathers per sample group -- 64 lines each -- are LDS
     // reads instead when the records of all points fit.
     __shared__ float4 s_tail[LDS_TAIL ? kLdsTailPoints : 1];
+    // Output timing (round 4).  A sample's 272-byte row of mlp_in is written in three 16-byte-per-lane pieces; the encoding
+    // half used to leave half-way through the trip and the aggregate at its end, ~1 us apart, and L2 evicted half-written
+    // lines in between: WRITE_SIZE was 1.26x the 276 B/sample the kernel produces (profiles/r03_pmc_hbm.json).  The
+    // encoding piece now waits in a lane-private LDS slot (no registers held across the row phase) and the three stores
+    // leave back to back at the end of the trip.
+    __shared__ float4 s_out[LDS_TAIL ? 768 : 256];
     if constexpr (LDS_TAIL) {
         for (int i = threadIdx.x; i < prm.P; i += blockDim.x) s_tail[i] = tailc[i];
         __syncthreads();
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
         float2 ev[2];
 #pragma unroll
         for (int a = 0; a < 2; a++) ev[a] = make_float2(__shfl(evt[a].x, tr), __shfl(evt[a].y, tr));
-        if (live) *reinterpret_cast<float4 *>(out + 36 + 4 * g) = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);
+        s_out[threadIdx.x] = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);      // (stored with the rest of the row, below)
 
         // ---- gather the 40 rows: 128 B of encoding per row across the 8 lanes, one owner lane's five rows ahead ----
         float agg[4] = {0.f, 0.f, 0.f, 0.f};
@@ -668,6 +674,7 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
         if (live) {
             *reinterpret_cast<float4 *>(out + 4 * g) = make_float4(agg[0], agg[1], agg[2], agg[3]);
             if (g == 0) *reinterpret_cast<float4 *>(out + 32) = make_float4(tail[0], tail[1], tail[2], var);
+            *reinterpret_cast<float4 *>(out + 36 + 4 * g) = s_out[threadIdx.x];
         }
         cur = nxt;
         i1 = i2;
