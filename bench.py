@@ -324,6 +324,12 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('OCC_FORCE_DEVICE', os.environ.get('LOCAL_RANK', 0)))
+    # Contract: rank 0 prints ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at communicator
+    # creation, through C stdio): keep a private handle on the real stdout for the line and send everything else --
+    # Python- and C-level -- to stderr.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; start it with '
                          f'--nproc-per-node {args.gpus}, or without a launcher (bench.py then starts its ranks itself)')
@@ -514,7 +520,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle.chain import model_context                  # the checker, timed as the stated CPU baseline
             line['cpu_baseline'] = cpu_baseline(model_context(0, False), frame, args.cpu_rays)
-        print(json.dumps(line))
+        json_out.write(json.dumps(line) + '\n')
+        json_out.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -349,7 +349,11 @@ class ShardedRenderer:
                 if k not in ('rays', 'near', 'far') and torch.is_tensor(v) and not v.is_cuda and v.numel() > 3:
                     local[k] = v.to(self.device, non_blocking=True)
             if ray_order_key is not None:
-                net_kwargs = dict(net_kwargs, ray_order_key=(ray_order_key, 'shard', self.rank, self.world))
+                # (the network caches the Morton order of the rays IT is handed per key: the key names this renderer's way of
+                # ordering / dealing them as well -- a single-process and a collective renderer of one process and camera
+                # hand over the same rays in different orders)
+                net_kwargs = dict(net_kwargs, ray_order_key=(ray_order_key, 'shard', self.rank, self.world, self.collective,
+                                                             self.block, self.morton, self.balance))
             out = self.net(**local, iter_val=iter_val, **net_kwargs)
             send[:n_mine, :3] = out['rgb']
             send[:n_mine, 3] = out['alpha']

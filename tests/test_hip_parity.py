@@ -1409,7 +1409,10 @@ def test_one_rank_rccl_group_runs_the_gather_path():
                           '--only', 'rccl_world1'], cwd=root, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     import json
-    line = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    # ONE line on stdout, the JSON line: RCCL's version banner (printed through C stdio at communicator creation) and any
+    # other library output go to stderr
+    assert len([l for l in res.stdout.splitlines() if l.strip()]) == 1, res.stdout[-1000:]
+    line = json.loads(res.stdout.strip())
     leg = line['rccl_world1']
     assert leg.get('backend') == 'nccl' and leg['world_size_formed'] == 1 and leg['collective'], leg
     assert leg['gathers_issued'] >= 4 and leg['plans_verified'] == 1 and leg['bit_identical_to_headline'], leg

@@ -231,7 +231,11 @@ def test_ray_sharding_gather_gloo(n_rays, world):
 
 
 class _FakeNet:                                           # renders rgb = f(ray) per ray, no coupling
-    def __call__(self, rays, near, far, iter_val=0, **_):
+    def __init__(self):
+        self.keys = []
+
+    def __call__(self, rays, near, far, iter_val=0, ray_order_key=None, **_):
+        self.keys.append(ray_order_key)
         return {'rgb': rays[0] * 2.0, 'alpha': near[:, 0] + 1.0, 'depth': far[:, 0] * 3.0}
 
     def live_samples_per_ray(self, rays, near, far, **_):
@@ -258,6 +262,12 @@ def _plan_worker(rank, world, port, mode, q):
             ok = ok and torch.equal(o['rgb'], d['rays'][0] * 2.0) and torch.equal(o['alpha'], d['near'][:, 0] + 1.0) \
                 and torch.equal(o['depth'], d['far'][:, 0] * 3.0)
         ok = ok and r.gathers_issued == 5 and r.plans_verified == 5       # (five different ray counts: five plans)
+        # the network caches the Morton order of the rays it is handed per ray_order_key: a single-process renderer and a
+        # collective one hand the same camera's rays over in different orders, so their keys must differ (round 4: they
+        # collided at world 1 and the collective render ran with the other renderer's permutation -- right pixels, no locality)
+        alone = ShardedRenderer(_FakeNet(), 'cpu', chunk=96, single=True)
+        alone.finish(alone.submit(frames[0][0], ray_order_key=frames[0][1]))
+        ok = ok and alone.net.keys[0] != r.net.keys[0] and alone.net.keys[0][0] == r.net.keys[0][0] == frames[0][1]
     else:
         mine = dict(data)
         if rank == 1 and mode == 'one_ray_less':
