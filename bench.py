@@ -434,9 +434,15 @@ def main():
             net.cfg.mlp_precision = 'bf16x3'
             net.invalidate_cache()
             dta, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
-            side['alt'] = {'mlp_precision': 'bf16x3 (hi/lo bf16 operands, 3 MFMA products, fp32 accumulate; parity-tested '
-                                            'to the same 1e-4 pixel gate)', 'value': R * args.steps / dta, 'unit': 'rays/s',
-                           'ms_per_step': dta / args.steps * 1e3}
+            net.cfg.dedup_repeated_samples = True          # ... and in the renderer's default configuration, like `dedup`
+            dtb, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
+            net.cfg.dedup_repeated_samples = False
+            side['alt'] = {'mlp_precision': 'bf16x3 (hi/lo bf16 operands, 3 MFMA products, fp32 accumulate): meets the 1e-4 pixel '
+                                            'gate on the random-init checkpoint, NOT on the trained-like one (alpha 1.5e-4, depth '
+                                            '9e-4: DESIGN.md 3.5); same device-side live list / repeated-sample elimination as fp32',
+                           'value': R * args.steps / dta, 'unit': 'rays/s', 'ms_per_step': dta / args.steps * 1e3,
+                           'default': {'dedup_repeated_samples': True, 'value': R * args.steps / dtb, 'unit': 'rays/s',
+                                       'ms_per_step': dtb / args.steps * 1e3}}
             net.cfg.mlp_precision = 'fp32'
             net.invalidate_cache()
         if leg('all_samples'):
