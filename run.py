@@ -46,11 +46,14 @@ def load_network(model):
 def _init_ranks():
     """One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE); a plain launch is world 1.
     OCC_DIST_BACKEND=gloo OCC_FORCE_DEVICE=0 (tests): several ranks share one GPU and exchange through the host -- RCCL
-    refuses two ranks per device; everything but the collective itself is then the production path."""
+    refuses two ranks per device; everything but the collective itself is then the production path.
+    OCC_FORCE_COLLECTIVE=1 under a launcher with ONE rank: the one-rank `nccl` group is formed too and ShardedRenderer takes
+    its N > 1 branch (plan, checksum all-gather, device-buffer gather, un-permutation) -- the RCCL path on a single-GPU box."""
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     torch.cuda.set_device(int(os.environ.get('OCC_FORCE_DEVICE', os.environ.get('LOCAL_RANK', 0))))
-    if world > 1 and not torch.distributed.is_initialized():
+    forced = 'WORLD_SIZE' in os.environ and os.environ.get('OCC_FORCE_COLLECTIVE', '0') == '1'
+    if (world > 1 or forced) and not torch.distributed.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = os.environ.get('OCC_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
@@ -73,7 +76,7 @@ def _setup(data_type, **loader_kw):
 
 
 def _finish_ranks(rank, world):
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
