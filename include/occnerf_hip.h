@@ -125,6 +125,15 @@ int occnerf_sample_warp(const float *rays, int64_t n, int32_t S, const float *t_
                         const float *t_rand, const float *Rs, const float *Ts, const float *vol,
                         int32_t nb, int32_t G, const float *h_bbox_min, const float *h_bbox_scale,
                         float *z_vals, float *pts, float *x_skel, float *mask, void *stream);
+/* The renderer's form (no jitter, no pts): same outputs, bit for bit, with the bones whose motion-weight channel cannot
+ * reach a wave's 64 samples skipped.  boxes[nb,6] int32 = {x0,x1,y0,y1,z0,z1} of every channel's non-zero voxels, from
+ * occnerf_bone_boxes on the same vol (x0 > x1: all zero).  The culling applies when S is a multiple of 64 (a wave's samples
+ * then lie on one ray); otherwise the call behaves like occnerf_sample_warp. */
+int occnerf_bone_boxes(const float *vol, int32_t nb, int32_t G, int32_t *boxes, void *stream);
+int occnerf_sample_warp_culled(const float *rays, int64_t n, int32_t S, const float *t_vals,
+                               const float *Rs, const float *Ts, const float *vol, int32_t nb, int32_t G,
+                               const int32_t *boxes, const float *h_bbox_min, const float *h_bbox_scale,
+                               float *z_vals, float *x_skel, float *mask, void *stream);
 
 /* Per-frame ray generation (one thread per pixel): camera_util.py:133-160 get_rays_from_KRT +
  * :163-212 rays_intersect_3d_bbox, as the reference's datasets call them (tpose.py:155-172,

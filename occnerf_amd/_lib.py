@@ -34,6 +34,8 @@ SIGNATURES = {
                                                 _u32, _u32, C.c_int, _vp]),
     'occnerf_sample_warp': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_bone_boxes': (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    'occnerf_sample_warp_culled': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_nonrigid_packed_floats': (_i64, []),
     'occnerf_nonrigid_pack': (C.c_int, [_vp, _vp, _vp, _vp]),
     'occnerf_nonrigid': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

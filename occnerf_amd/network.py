@@ -313,7 +313,7 @@ class Network(nn.Module):
             s = self._producer = torch.cuda.Stream(device=dev, priority=int(os.environ.get('OCC_PRODUCER_PRIORITY', '-1')))
         return s
 
-    def _render_overlapped(self, chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, table, pack):
+    def _render_overlapped(self, chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, table, pack, boxes=None):
         """The frame's rays in `chunks` = [(rays8 slice, out_rows slice or None, out tensors)], software-pipelined over two streams: chunk k + 1's
         sampler / warp / non-rigid MLP / kNN / feature kernels (producer stream) run while chunk k's canonical MLP and
         compositing do (the caller's stream).  The kNN kernel is VALU-bound and the feature kernel texture-path-bound; the
@@ -328,7 +328,7 @@ class Network(nn.Module):
         prod.wait_stream(main)
         for rays8, out_rows, out in chunks:
             with torch.cuda.stream(prod):
-                z, xyz, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale)
+                z, xyz, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale, boxes=boxes)
                 st = self._stage_features(rays8, z, xyz, mask, pk, cond, hann, table, pack)
                 del xyz
                 ready = prod.record_event()
@@ -341,7 +341,7 @@ class Network(nn.Module):
         # (nothing to join: the consumer stream is the caller's, and every producer kernel precedes a consumer wait)
 
     def _render_rays(self, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann,
-                     table, t_rand=None, out=None, out_rows=None, pack=None):
+                     table, t_rand=None, out=None, out_rows=None, pack=None, boxes=None):
         """out: (rgb[R,3], alpha[R], depth[R]) of the whole frame; this pass's rays land in rows out_rows (their index
         in the caller's order) or, without a permutation, in the slice the caller passes."""
         cfg, ctx = self.cfg, self._context()
@@ -349,7 +349,7 @@ class Network(nn.Module):
         enc = self.cnl_mlp.module.encoder
         t_vals = torch.linspace(0., 1., steps=S, device=rays8.device)
         z, xyz, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale,
-                                          t_rand=t_rand)
+                                          t_rand=t_rand, boxes=boxes)
         pk = self._packed_weights()
         # Samples whose motion-weight sum is exactly 0 (outside every bone's prior support or outside the
         # canonical volume) cannot contribute: their alpha is multiplied by that sum (network.py:330).  They
@@ -412,8 +412,9 @@ class Network(nn.Module):
         rays8 = ops.pack_rays(f32(rays).reshape(2, -1, 3), f32(near).reshape(-1), f32(far).reshape(-1), None)
         S = int(cfg.N_samples)
         t_vals = torch.linspace(0., 1., steps=S, device=dev)
+        boxes = ops.bone_boxes(vol, Rs.shape[0]) if cfg.get('warp_bone_culling', True) else None
         _, _, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, self._host3(kwargs['cnl_bbox_min_xyz']),
-                                        self._host3(kwargs['cnl_bbox_scale_xyz']))
+                                        self._host3(kwargs['cnl_bbox_scale_xyz']), boxes=boxes)
         return (mask.view(-1, S) != 0).sum(dim=1)
 
     def forward(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None,
@@ -473,6 +474,9 @@ class Network(nn.Module):
                 Rs, Ts = ops.pose_motion_bases(self.pose_decoder, f32(dst_posevec).reshape(-1), refine, f32(dst_Rs[0]),
                                                f32(dst_Ts[0]), f32(cnl_gtfms[0]))
                 vol = ops.prior_softmax(wc['dec'], f32(motion_weights_priors[0]))
+                # support box of every bone's weight channel (one tiny launch): the warp kernel skips the bones that cannot
+                # reach a wave's samples -- same bits (cfg.warp_bone_culling=False: every bone for every sample)
+                boxes = ops.bone_boxes(vol, Rs.shape[0]) if cfg.get('warp_bone_culling', True) else None
                 cond = f32(dst_posevec).reshape(-1) if iter_val >= nr.kick_in_iter else \
                     torch.zeros(dst_posevec.numel(), device=dev)
                 rays_f = f32(torch.stack([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)]) if not torch.is_tensor(rays) else
@@ -493,15 +497,15 @@ class Network(nn.Module):
                     chunks = [(rays8[i:i + per], None if order is None else order[i:i + per],
                                out if order is not None else tuple(t[i:i + per] for t in out)) for i in range(0, R, per)]
                     self._render_overlapped(chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                            wc['table'], pack)
+                                            wc['table'], pack, boxes)
                 for i in range(0, 0 if overlap else R, rays_per_pass):
                     n = min(rays_per_pass, R - i)
                     if order is not None:
                         self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                          wc['table'], out=out, out_rows=order[i:i + n], pack=pack)
+                                          wc['table'], out=out, out_rows=order[i:i + n], pack=pack, boxes=boxes)
                     else:
                         self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                          wc['table'], out=tuple(t[i:i + n] for t in out), pack=pack)
+                                          wc['table'], out=tuple(t[i:i + n] for t in out), pack=pack, boxes=boxes)
                 rgb, acc, depth = out
                 comp_loss = torch.zeros(1, device=dev)
         else:

@@ -204,10 +204,34 @@ def gen_rays(K, E, H, W, bbox_min, bbox_max, device):
 
 
 # ------------------------------------------------------------------ sample pipeline (section 2)
-def sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale, t_rand=None, want_pts=False):
-    """rays8[n,8] -> z_vals[n,S], x_skel[n*S,3], mask[n*S] (, pts[n*S,3])."""
+def bone_boxes(vol, nb):
+    """int32[nb,6] = {x0,x1,y0,y1,z0,z1}: index box of the non-zero voxels of every bone's motion-weight channel."""
+    boxes = torch.empty(nb, 6, device=vol.device, dtype=torch.int32)
+    with _guard(vol):
+        rc = _lib.lib().occnerf_bone_boxes(_chk(vol, torch.float32, 'vol'), int(nb), int(vol.shape[-1]), boxes.data_ptr(), _stream(vol))
+    _lib.check(rc, 'bone_boxes')
+    return boxes
+
+
+def sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale, t_rand=None, want_pts=False, boxes=None):
+    """rays8[n,8] -> z_vals[n,S], x_skel[n*S,3], mask[n*S] (, pts[n*S,3]).  boxes (ops.bone_boxes of the same vol; render only:
+    no jitter, no pts): bones that cannot reach a wave's samples are skipped, same bits."""
     n = rays8.shape[0]
     dev = rays8.device
+    if boxes is not None and t_rand is None and not want_pts:
+        z = torch.empty(n, S, device=dev, dtype=torch.float32)
+        xs = torch.empty(n * S, 3, device=dev, dtype=torch.float32)
+        mk = torch.empty(n * S, device=dev, dtype=torch.float32)
+        _kmin, pmin = _host_f32(bbox_min, 3)
+        _ksc, psc = _host_f32(bbox_scale, 3)
+        with _guard_dev(dev):
+            rc = _lib.lib().occnerf_sample_warp_culled(
+                _chk(rays8, torch.float32, 'rays'), n, int(S), _chk(t_vals, torch.float32, 't_vals'),
+                _chk(Rs, torch.float32, 'Rs'), _chk(Ts, torch.float32, 'Ts'), _chk(vol, torch.float32, 'vol'), int(Rs.shape[0]),
+                int(vol.shape[-1]), _chk(boxes, torch.int32, 'boxes'), pmin, psc, z.data_ptr(), xs.data_ptr(), mk.data_ptr(),
+                _stream(rays8))
+        _lib.check(rc, 'sample_warp_culled')
+        return z, xs, mk, None
     z = torch.empty(n, S, device=dev, dtype=torch.float32)
     xs = torch.empty(n * S, 3, device=dev, dtype=torch.float32)
     mk = torch.empty(n * S, device=dev, dtype=torch.float32)

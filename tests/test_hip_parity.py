@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from tests import util
-from tests.gpu_util import build_network, frame_to_device, stagewise_oracle_render
+from tests.gpu_util import build_network, frame_to_device, per_frame_cpu, stagewise_oracle_render
 
 pytestmark = pytest.mark.gpu
 
@@ -587,6 +587,43 @@ def test_canonical_mlp_module_gathered_interface(case, ops):
     want = g['cnl.raw']
     assert np.abs(raw.cpu().numpy()[:, 4] - want[:, 4]).max() <= 1e-6
     assert np.abs(raw.cpu().numpy()[:, :4] - want[:, :4]).max() <= util.pick(g, 2e-5, 5e-4, 2e-2)
+
+
+def test_warp_bone_culling_is_exact(ops, oracle):
+    """Round 4: the warp kernel skips, per wave of 64 samples of one ray, the bones whose motion-weight channel (its non-zero
+    support box from occnerf_bone_boxes, widened by the tap reach) cannot reach those samples.  Every skipped (sample, bone)
+    pair would have contributed a weight of exactly +0: z, x_skel and the motion-weight sum are bit-identical to the unculled
+    kernel -- on posed frames at S = 64 / 128 / 192, rays that miss the body included -- the support boxes equal numpy's, and
+    with S not a multiple of 64 the call falls back to every bone."""
+    from occnerf_amd import synth
+    ctx = util.model_context(0, False)
+    for size, S, pose in ((64, 64, 1), (96, 128, 3), (64, 192, 5), (48, 96, 2)):
+        frame = synth.make_frame(img_size=size, pose72=synth.seeded_pose(pose), orbit_frame=17 * pose)
+        Rs, Ts, vol, hann, cond = per_frame_cpu(ctx, frame)
+        rays8 = T(np.concatenate([frame['rays'][0], frame['rays'][1], frame['near'], frame['far']], -1).astype(np.float32))
+        t_vals = torch.linspace(0., 1., steps=S, device=DEV)
+        vd = T(vol)
+        boxes = ops.bone_boxes(vd, 24)
+        v = vol[:24]
+        for b in range(24):
+            nz = np.argwhere(v[b] != 0)                     # (z, y, x)
+            want = [G for G in (32, -1) * 3] if nz.size == 0 else [nz[:, 2].min(), nz[:, 2].max(), nz[:, 1].min(), nz[:, 1].max(),
+                                                                    nz[:, 0].min(), nz[:, 0].max()]
+            assert boxes[b].tolist() == [int(x) for x in want], b
+        a = ops.sample_warp(rays8, S, t_vals, T(Rs), T(Ts), vd, frame['cnl_bbox_min_xyz'], frame['cnl_bbox_scale_xyz'])
+        c = ops.sample_warp(rays8, S, t_vals, T(Rs), T(Ts), vd, frame['cnl_bbox_min_xyz'], frame['cnl_bbox_scale_xyz'], boxes=boxes)
+        for x, y, name in zip(a[:3], c[:3], ('z', 'x_skel', 'mask')):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (size, S, name)
+        assert float(a[2].max()) > 0.5 and float((a[2] == 0).float().mean()) > 0.1
+    # a channel that is zero everywhere and one that fills the grid
+    vz = vd.clone()
+    vz[3] = 0
+    vz[5] = 1e-3
+    bz = ops.bone_boxes(vz, 24)
+    assert bz[3, 0] > bz[3, 1] and bz[5].tolist() == [0, 31, 0, 31, 0, 31]
+    a = ops.sample_warp(rays8, 64, torch.linspace(0., 1., 64, device=DEV), T(Rs), T(Ts), vz, frame['cnl_bbox_min_xyz'], frame['cnl_bbox_scale_xyz'])
+    c = ops.sample_warp(rays8, 64, torch.linspace(0., 1., 64, device=DEV), T(Rs), T(Ts), vz, frame['cnl_bbox_min_xyz'], frame['cnl_bbox_scale_xyz'], boxes=bz)
+    assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(a[:3], c[:3]))
 
 
 # ----------------------------------------------------------------------------- a9
