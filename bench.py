@@ -86,7 +86,8 @@ def cpu_baseline(ctx, frame, n_rays):
 def pmc_traffic(n_samples):
     """HBM bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 cannot run
     inside this process); only quoted when it was collected at the same launch size."""
-    for name in ('r03_pmc_hbm.json', 'r02_pmc_hbm.json', 'r01_pmc_hbm.json'):
+    import glob
+    for name in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm.json'))), reverse=True):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if abs(int(d['samples_per_launch']) - int(n_samples)) <= 1:
