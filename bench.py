@@ -39,7 +39,8 @@ camera, one frame of lag, device image assembly, uint8 D2H), rays/s over a whole
 `per_rank_live_samples` show the balance of the shard plan.  `rccl_world1` (N = 1): the same frame through the N > 1
 branch of the sharded renderer with a ONE-rank `nccl` process group (plan + checksum all-gather, padded send buffer,
 asynchronous dist.gather on device buffers, work.wait(), un-permutation): what a single-GPU box can execute of the
-multi-GPU path; pixels bit-identical to the headline's, never part of `value`.
+multi-GPU path; pixels bit-identical to the headline's, never part of `value`.  It runs in a CHILD process under a time limit
+(this script again with a few headline frames of its own), so that a communicator that hangs cannot take the headline line down.
 """
 import argparse
 import json
@@ -312,6 +313,7 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=4096, help='rays in the CPU baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the side measurements (bf16x3, all samples, train)')
+    ap.add_argument('--rccl-inline', action='store_true', help=argparse.SUPPRESS)      # (the child process of the rccl_world1 leg)
     ap.add_argument('--only', default=None, help='comma-separated side legs to run beside the headline (default: all): '
                                                  'dedup,rccl_world1,alt,all_samples,train,movement,config4,overlap')
     args = ap.parse_args()
@@ -426,9 +428,24 @@ def main():
         net.cfg.dedup_repeated_samples = False
     if world == 1:
         if leg('rccl_world1'):
+            # A side leg never takes the headline down -- not even by hanging inside a communicator: unless this IS the
+            # child, the leg runs in a child process (this script with --rccl-inline: its own few headline frames, then the
+            # one-rank nccl group) under a time limit, and only its `rccl_world1` object is taken over.
             try:
-                side['rccl_world1'] = rccl_world1_leg(net, frame_h, dev, max(3, args.steps // 2), headline_out.to(dev), host_out)
-            except Exception as e:                                   # a side leg never takes the headline down
+                if args.rccl_inline:
+                    side['rccl_world1'] = rccl_world1_leg(net, frame_h, dev, max(3, args.steps // 2), headline_out.to(dev), host_out)
+                else:
+                    import subprocess
+                    child = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps',
+                                            str(max(3, args.steps // 2)), '--warmup', '2', '--no-cpu-baseline', '--only', 'rccl_world1',
+                                            '--rccl-inline'], capture_output=True, text=True, timeout=300,
+                                           env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+                    lines = [l for l in child.stdout.splitlines() if l.startswith('{')]
+                    if child.returncode != 0 or not lines:
+                        raise RuntimeError(f'child rc {child.returncode}: {child.stderr[-300:]}')
+                    cl = json.loads(lines[-1])
+                    side['rccl_world1'] = dict(cl['rccl_world1'], headline_ms_per_step_in_child=cl['ms_per_step'])
+            except Exception as e:
                 side['rccl_world1'] = {'error': f'{type(e).__name__}: {e}'[:400]}
         if leg('alt'):
             # opt-in split-bf16 MLP path (cfg.mlp_precision='bf16x3'): same frame, same steps; never part of `value`
