@@ -261,6 +261,13 @@ def run_case(name, img_size, S, amplify, pose=None, orbit_frame=0, non_rigid=Fal
         bad = fragile_rays(rec.d['cnl.xyz'], rec.d['comp.mask'].reshape(len(sel), -1), net)
         print(f'   tie-free fixture: {int(bad.sum())} of {len(sel)} candidate rays hold a live sample within 2e-5 (relative) of a '
               'neighbour-set / inside-vote discontinuity: dropped')
+        # nothing is hidden: the dropped rays and what the reference rendered for them travel with the fixture (`dropped.*`),
+        # and the parity test renders them too -- held to a bound that a flipped neighbour set stays within, with the number of
+        # them beyond the gate printed
+        dropped = {'dropped.ray_select': sel[bad], 'dropped.rays': full['rays'][:, sel[bad]], 'dropped.near': full['near'][sel[bad]],
+                   'dropped.far': full['far'][sel[bad]]}
+        for k in ('rgb', 'alpha', 'depth'):
+            dropped['dropped.out.' + k] = _np(out[k])[bad]
         sel = sel[~bad][:keep_rays]
         net, sd, rec, out = reference_pass(sel)
         assert not fragile_rays(rec.d['cnl.xyz'], rec.d['comp.mask'].reshape(len(sel), -1), net).any()
@@ -292,6 +299,8 @@ def run_case(name, img_size, S, amplify, pose=None, orbit_frame=0, non_rigid=Fal
     g['mw.vol_sum'] = np.float64(vol.astype(np.float64).sum())
     for k in ('rgb', 'alpha', 'depth'):
         g['out.' + k] = _np(out[k])
+    if tie_free:
+        g.update(dropped)
     g['model.fps0'], g['model.fps1'], g['model.fps2'] = [_np(f) for f in net.fps_index]
     g['model.point_norms_digest'] = checkpoint.tensor_digest(net.point_norms)
     g['model.ranges_y'] = _np(net.ranges_y)
