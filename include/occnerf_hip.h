@@ -229,6 +229,22 @@ int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t n_rays,
                             const int32_t *h_coarse_rows, const int32_t *h_seed_from_coarser,
                             int32_t nscale, const int32_t *query_rows, const int32_t *n_query_dev, int32_t *ray_start,
                             int32_t *knn_idxs, void *stream);
+/* Centre cache.  occnerf_knn_center searches ONE point c[3] (device memory) against the brute-force layout of occnerf_msknn
+ * (points[M,4], index_map[M], h_scale_begin[nscale+1]) and writes center_out[4] = (c, r^2) and idx_out[nscale,10]: c's neighbours
+ * and the squared radius inside which every query provably has the same neighbours in the same order (0: none, e.g. a tie among
+ * c's 11 nearest).  occnerf_msknn_clustered_centered is occnerf_msknn_clustered with that pair (nullable together): queries with
+ * |q - c|^2 < r^2 receive idx_out without a search, tiles that hold no other query are skipped.  Same knn_idxs, bit for bit.
+ * The renderer passes c = the non-rigid offset of the origin, onto which the samples with a vanishing motion-weight sum
+ * collapse (two thirds of the live samples of a frame). */
+int occnerf_knn_center(const float *c, const float *points, const int32_t *index_map, const int32_t *h_scale_begin,
+                       int32_t nscale, float *center_out, int32_t *idx_out, void *stream);
+int occnerf_msknn_clustered_centered(const float *xyz, const float *mask, int64_t n_rays, int32_t samples_per_ray,
+                                     const float *points, const float *centers,
+                                     const int32_t *cluster_ranges, const float *cluster_radius, int32_t ncl,
+                                     const float *group_centers, const int32_t *group_ranges, const float *group_radius, int32_t ngrp,
+                                     const int32_t *h_coarse_rows, const int32_t *h_seed_from_coarser,
+                                     int32_t nscale, const int32_t *query_rows, const int32_t *n_query_dev, int32_t *ray_start,
+                                     const float *center, const int32_t *center_idx, int32_t *knn_idxs, void *stream);
 
 /* Plain exact kNN for small problems (k <= 16): idx[nq,k] rows of s, ascending.
  * Used for the per-point k=3 search of network.py:265-269 and the k=10 visibility update

@@ -47,6 +47,9 @@ SIGNATURES = {
     'occnerf_msknn': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     'occnerf_msknn_clustered': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
                                            _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_msknn_clustered_centered': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
+                                           _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_knn_center': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     'occnerf_knn_small': (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'occnerf_unit_normals': (C.c_int, [_vp, _i32, _vp, _vp]),
     'occnerf_point_sdf': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

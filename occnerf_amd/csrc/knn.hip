@@ -199,6 +199,78 @@ __device__ __forceinline__ void consider_lex(KBest64 &b, float &thr, float &sb, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// CENTRE CACHE (round 4).  Two thirds of a frame's live samples sit within a micrometre of ONE point: wherever a sample's
+// motion-weight sum is far below the reference's 1e-4 clamp (network.py:388) its warped position collapses onto the origin, and
+// after the non-rigid offset onto c = offset(0).  knn_center_kernel searches c once per frame -- the 11 nearest points of every
+// scale, by the very distance formula and (distance, row) order of the search kernels -- and derives a radius r inside which
+// EVERY query provably has c's neighbours in c's order: a query q moves every true distance by at most |q - c| and the computed
+// fp32 distance (correctly rounded sqrt of an fma chain) is within 2e-7 relative of the true one, so with g = the smallest gap
+// between consecutive ones of c's 11 computed distances over all scales (d_1 .. d_11; every other point is at least d_11 away),
+// r = 0.9 (g / 2 - 2e-6 (d_11max + 1)) keeps every pair (a, b) with d_c(a) < d_c(b) in that order at q.  A tie among c's 11
+// (g = 0) disables the cache.  msknn_clustered_kernel then takes the queries with |q - c|^2 < r^2 out of the search, writes c's
+// indices for them, and skips tiles that hold no other query: same indices as the search, bit for bit (tested against the
+// brute-force kernel with queries just inside and just outside r, and on the tie model).
+__global__ __launch_bounds__(256) void knn_center_kernel(const float *__restrict__ c, const float4 *__restrict__ points,
+                                                         const int32_t *__restrict__ index_map, MsKnnScales sc,
+                                                         float *__restrict__ center_out /*[4]: c, r^2*/,
+                                                         int32_t *__restrict__ idx_out /*[nscale][10]*/) {
+    __shared__ float s_d[256];
+    __shared__ int s_r[256];
+    __shared__ float s_sel_d[11];
+    __shared__ int s_sel_r[11];
+    __shared__ float s_gap, s_dmax;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    if (threadIdx.x == 0) s_gap = INFINITY, s_dmax = 0.0f;
+    __syncthreads();
+    for (int l = 0; l < sc.nscale; l++) {
+        const int jb = sc.begin[l], je = sc.end[l];
+        float last_d = -1.0f;
+        int last_r = -1;
+        for (int round = 0; round < 11; round++) {
+            // smallest (distance, row) strictly above the last one taken
+            float bd = INFINITY;
+            int br = 0x7fffffff;
+            for (int j = jb + threadIdx.x; j < je; j += blockDim.x) {
+                const float4 P = points[j];
+                const float dx = cx - P.x, dy = cy - P.y, dz = cz - P.z;
+                const float d = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+                const int row = j - jb;
+                const bool after = d > last_d || (d == last_d && row > last_r);
+                if (after && (d < bd || (d == bd && row < br))) bd = d, br = row;
+            }
+            s_d[threadIdx.x] = bd, s_r[threadIdx.x] = br;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) {
+                    const float od = s_d[threadIdx.x + o];
+                    const int orow = s_r[threadIdx.x + o];
+                    if (od < s_d[threadIdx.x] || (od == s_d[threadIdx.x] && orow < s_r[threadIdx.x]))
+                        s_d[threadIdx.x] = od, s_r[threadIdx.x] = orow;
+                }
+                __syncthreads();
+            }
+            last_d = s_d[0], last_r = s_r[0];
+            if (threadIdx.x == 0) s_sel_d[round] = last_d, s_sel_r[round] = last_r;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float g = s_gap;
+            for (int j = 0; j < 10; j++) g = fminf(g, s_sel_d[j + 1] - s_sel_d[j]);      // (inf - x: a scale with < 11 real points...)
+            if (!(s_sel_d[10] < INFINITY)) g = 0.0f;                                    // ... disables the cache
+            s_gap = g;
+            s_dmax = fmaxf(s_dmax, s_sel_d[10] < INFINITY ? s_sel_d[10] : 0.0f);
+        }
+        if (threadIdx.x < 10) idx_out[l * 10 + threadIdx.x] = index_map[jb + s_sel_r[threadIdx.x]];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float r = 0.9f * (0.5f * s_gap - 2e-6f * (s_dmax + 1.0f));
+        center_out[0] = cx, center_out[1] = cy, center_out[2] = cz;
+        center_out[3] = (r > 0.0f && r < INFINITY) ? r * r : 0.0f;
+    }
+}
+
 struct ClusteredScales {
     int nscale, ncl, ngrp;
     int coarse_begin, coarse_end;   // rows of the coarsest scale (original order, padded to 4)
@@ -213,8 +285,12 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     const float *__restrict__ gradius /*[nscale-1][ngrp], < 0: empty*/,
     ClusteredScales sc, int32_t *__restrict__ knn_idxs, unsigned *__restrict__ ticket,
     const int32_t *__restrict__ qrows /*nullable: ascending list of the samples to query*/,
-    const int32_t *__restrict__ ray_start /*with qrows: [n_rays + 1] first list entry of every ray*/) {
+    const int32_t *__restrict__ ray_start /*with qrows: [n_rays + 1] first list entry of every ray*/,
+    const float *__restrict__ center /*nullable: knn_center_kernel's [4] (c, r^2)*/,
+    const int32_t *__restrict__ center_idx /*with center: c's indices [nscale][10]*/) {
     const int lane = threadIdx.x & 63;
+    float ccx = 0.f, ccy = 0.f, ccz = 0.f, cr2 = 0.f;      // wave-uniform (scalar loads)
+    if (center) ccx = center[0], ccy = center[1], ccz = center[2], cr2 = center[3];
     const int tiles_per_chunk = (S + 3) / 4;
     const int64_t n_tiles = ((n_rays + 63) / 64) * tiles_per_chunk;
     // Tiles differ widely in cost (a tile of dead samples is skipped after its mask loads, a tile near the body
@@ -265,7 +341,27 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
             qy[a >> 1][a & 1] = xyz[qi[a] * 3 + 1];
             qz[a >> 1][a & 1] = xyz[qi[a] * 3 + 2];
         }
-        if (__builtin_amdgcn_ballot_w64(live[0] || live[1] || live[2] || live[3]) == 0) continue;   // whole tile dead
+        // centre cache: queries provably inside the radius in which c's neighbour lists hold leave the search with c's indices
+        if (cr2 > 0.0f) {
+#pragma unroll
+            for (int a = 0; a < kQ; a++) {
+                const float dx = qx[a >> 1][a & 1] - ccx, dy = qy[a >> 1][a & 1] - ccy, dz = qz[a >> 1][a & 1] - ccz;
+                const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                if (live[a] && d2 < cr2) {
+                    live[a] = false;
+                    struct __attribute__((packed, aligned(4))) I4 { int v[4]; };
+                    struct __attribute__((packed, aligned(4))) I2 { int v[2]; };
+                    for (int l = 0; l < sc.nscale; l++) {
+                        int32_t *out = knn_idxs + (qi[a] * sc.nscale + l) * kK;
+                        const int32_t *ci = center_idx + l * kK;
+                        *reinterpret_cast<I4 *>(out) = I4{{ci[0], ci[1], ci[2], ci[3]}};
+                        *reinterpret_cast<I4 *>(out + 4) = I4{{ci[4], ci[5], ci[6], ci[7]}};
+                        *reinterpret_cast<I2 *>(out + 8) = I2{{ci[8], ci[9]}};
+                    }
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(live[0] || live[1] || live[2] || live[3]) == 0) continue;   // whole tile dead (or served by the cache)
         KBest64 best[kQ];
         float thr[kQ], sb[kQ];
 
@@ -510,6 +606,24 @@ __global__ void ray_list_ranges_kernel(const int32_t *__restrict__ qrows, const 
 }
 }  // namespace occ
 
+OCC_API int occnerf_knn_center(const float *c, const float *points, const int32_t *index_map,
+                               const int32_t *h_scale_begin, int32_t nscale, float *center_out, int32_t *idx_out, void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(c && points && index_map && h_scale_begin && center_out && idx_out, "knn_center: null argument");
+    OCC_REQUIRE(nscale >= 1 && nscale <= 4, "knn_center: nscale=%d unsupported (1..4)", nscale);
+    MsKnnScales sc;
+    sc.nscale = nscale;
+    for (int l = 0; l < nscale; l++) {
+        sc.begin[l] = h_scale_begin[l];
+        sc.end[l] = h_scale_begin[l + 1];
+        sc.seed[l] = 0;
+        OCC_REQUIRE(sc.end[l] - sc.begin[l] >= kK, "knn_center: scale %d has fewer than %d points", l, kK);
+    }
+    hipLaunchKernelGGL(knn_center_kernel, dim3(1), dim3(256), 0, as_stream(stream), c, reinterpret_cast<const float4 *>(points),
+                       index_map, sc, center_out, idx_out);
+    return check_launch("knn_center");
+}
+
 OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t n_rays, int32_t samples_per_ray,
                                     const float *points,
                                     const float *centers, const int32_t *cluster_ranges,
@@ -519,7 +633,23 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t
                                     const int32_t *h_seed_from_coarser, int32_t nscale,
                                     const int32_t *query_rows, const int32_t *n_query_dev, int32_t *ray_start,
                                     int32_t *knn_idxs, void *stream) {
+    return occnerf_msknn_clustered_centered(xyz, mask, n_rays, samples_per_ray, points, centers, cluster_ranges, cluster_radius, ncl,
+                                            group_centers, group_ranges, group_radius, ngrp, h_coarse_rows, h_seed_from_coarser,
+                                            nscale, query_rows, n_query_dev, ray_start, nullptr, nullptr, knn_idxs, stream);
+}
+
+OCC_API int occnerf_msknn_clustered_centered(const float *xyz, const float *mask, int64_t n_rays, int32_t samples_per_ray,
+                                             const float *points,
+                                             const float *centers, const int32_t *cluster_ranges,
+                                             const float *cluster_radius, int32_t ncl, const float *group_centers,
+                                             const int32_t *group_ranges, const float *group_radius, int32_t ngrp,
+                                             const int32_t *h_coarse_rows,
+                                             const int32_t *h_seed_from_coarser, int32_t nscale,
+                                             const int32_t *query_rows, const int32_t *n_query_dev, int32_t *ray_start,
+                                             const float *center, const int32_t *center_idx,
+                                             int32_t *knn_idxs, void *stream) {
     using namespace occ;
+    OCC_REQUIRE(!center == !center_idx, "msknn_clustered: center and center_idx come together (occnerf_knn_center)");
     if (n_rays <= 0 || samples_per_ray <= 0) return 0;
     OCC_REQUIRE((!query_rows && !n_query_dev && !ray_start) || (query_rows && n_query_dev && ray_start),
                 "msknn_clustered: query_rows, n_query_dev and the ray_start scratch come together");
@@ -576,7 +706,8 @@ OCC_API int occnerf_msknn_clustered(const float *xyz, const float *mask, int64_t
                        n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points),
                        reinterpret_cast<const float4 *>(centers), reinterpret_cast<const int2 *>(cluster_ranges),
                        cluster_radius, reinterpret_cast<const float4 *>(group_centers),
-                       reinterpret_cast<const int2 *>(group_ranges), group_radius, sc, knn_idxs, ticket, query_rows, ray_start);
+                       reinterpret_cast<const int2 *>(group_ranges), group_radius, sc, knn_idxs, ticket, query_rows, ray_start,
+                       center, center_idx);
     return check_launch("msknn_clustered");
 }
 

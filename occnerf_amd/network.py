@@ -234,7 +234,7 @@ class Network(nn.Module):
         return table
 
     # ------------------------------------------------------------------ sample pipeline
-    def _stage_features(self, rays8, z, xyz, mask, pk, cond, hann, table, pack):
+    def _stage_features(self, rays8, z, xyz, mask, pk, cond, hann, table, pack, center=None):
         """First half of a pass on the live-sample list (VALU / texture-path kernels + the non-rigid MLP): live list, non-rigid
         offsets, repeated-sample heads, kNN, features.  -> state for `_stage_mlp_composite`.  List and count of the live samples
         stay on the device: no host round trip in the frame."""
@@ -265,9 +265,9 @@ class Network(nn.Module):
                 frows, fcount = ops.unique_heads(xyz, 3, frows, fcount, scan=scan_a, scan_count=count)
         self.last_head_counts = (fcount, None)
         if cfg.get('knn_query_list', True):    # tiles formed over the listed samples only (same indices, tested)
-            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], rows=frows, count=fcount)
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], rows=frows, count=fcount, center=center)
         else:
-            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=kmask)
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=kmask, center=center)
         mlp_in, raw_c, _ = ops.sample_features(
             xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
@@ -305,6 +305,17 @@ class Network(nn.Module):
         st['mlp_in'] = None
         return ops.composite(raw, st['mask'], st['z'], st['rays8'], bgcolor, out=out, out_rows=out_rows)[:3]
 
+    def _knn_center(self, cond, hann):
+        """(center, idx) of ops.knn_center for this frame's collapse point: wherever a sample's motion-weight sum is far below
+        the 1e-4 clamp of the reference's warp (network.py:388) its warped position lands within a micrometre of the origin,
+        hence -- after the non-rigid offset -- of offset(0): two thirds of a frame's live samples.  The kNN kernel hands those
+        queries c's neighbour lists when they lie inside the radius in which the lists provably hold (exact: DESIGN.md 3.2)."""
+        ctx, pk = self._context(), self._packed_weights()
+        c = torch.zeros(64, 3, device=self.point_base.device)
+        if not self.cfg.ignore_non_rigid_motions:
+            c = ops.nonrigid(c, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
+        return ops.knn_center(c[0].contiguous(), ctx['points'], ctx['index_map'], ctx['scale_begin'])
+
     def _side_stream(self, dev):
         """The producer stream of the overlapped render (high priority: its small VALU / texture-path workgroups take the
         slots the matrix-pipe kernel's retiring workgroups free)."""
@@ -313,7 +324,7 @@ class Network(nn.Module):
             s = self._producer = torch.cuda.Stream(device=dev, priority=int(os.environ.get('OCC_PRODUCER_PRIORITY', '-1')))
         return s
 
-    def _render_overlapped(self, chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, table, pack, boxes=None):
+    def _render_overlapped(self, chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, table, pack, boxes=None, center=None):
         """The frame's rays in `chunks` = [(rays8 slice, out_rows slice or None, out tensors)], software-pipelined over two streams: chunk k + 1's
         sampler / warp / non-rigid MLP / kNN / feature kernels (producer stream) run while chunk k's canonical MLP and
         compositing do (the caller's stream).  The kNN kernel is VALU-bound and the feature kernel texture-path-bound; the
@@ -329,7 +340,7 @@ class Network(nn.Module):
         for rays8, out_rows, out in chunks:
             with torch.cuda.stream(prod):
                 z, xyz, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale, boxes=boxes)
-                st = self._stage_features(rays8, z, xyz, mask, pk, cond, hann, table, pack)
+                st = self._stage_features(rays8, z, xyz, mask, pk, cond, hann, table, pack, center)
                 del xyz
                 ready = prod.record_event()
             main.wait_event(ready)
@@ -341,7 +352,7 @@ class Network(nn.Module):
         # (nothing to join: the consumer stream is the caller's, and every producer kernel precedes a consumer wait)
 
     def _render_rays(self, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann,
-                     table, t_rand=None, out=None, out_rows=None, pack=None, boxes=None):
+                     table, t_rand=None, out=None, out_rows=None, pack=None, boxes=None, center=None):
         """out: (rgb[R,3], alpha[R], depth[R]) of the whole frame; this pass's rays land in rows out_rows (their index
         in the caller's order) or, without a permutation, in the slice the caller passes."""
         cfg, ctx = self.cfg, self._context()
@@ -358,7 +369,7 @@ class Network(nn.Module):
         N = xyz.shape[0]
         if cfg.get('skip_empty_samples', True) and cfg.get('knn_culling', True):
             # (fp32 and the opt-in split-bf16 kernels alike: list and count of the live samples on the device, no host sync)
-            st = self._stage_features(rays8, z, xyz, mask, pk, cond, hann, table, pack)
+            st = self._stage_features(rays8, z, xyz, mask, pk, cond, hann, table, pack, center)
             return self._stage_mlp_composite(st, bgcolor, out, out_rows)
 
         # every sample evaluated (cfg.skip_empty_samples off) and / or the brute-force neighbour search (cfg.knn_culling off)
@@ -368,7 +379,7 @@ class Network(nn.Module):
             else:
                 ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
         if cfg.get('knn_culling', True):     # same results, ~5x fewer distance evaluations
-            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'])
+            knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], center=center)
         else:
             knn = ops.msknn(xyz, ctx['points'], ctx['index_map'], ctx['scale_begin'], ctx['seed'])
         mlp_in, raw, _ = ops.sample_features(
@@ -479,6 +490,7 @@ class Network(nn.Module):
                 boxes = ops.bone_boxes(vol, Rs.shape[0]) if cfg.get('warp_bone_culling', True) else None
                 cond = f32(dst_posevec).reshape(-1) if iter_val >= nr.kick_in_iter else \
                     torch.zeros(dst_posevec.numel(), device=dev)
+                center = self._knn_center(cond, hann.tolist()) if cfg.get('knn_center_cache', True) and cfg.get('knn_culling', True) else None
                 rays_f = f32(torch.stack([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)]) if not torch.is_tensor(rays) else
                              rays.reshape(2, -1, 3))
                 order = morton_order(rays_f[1])
@@ -497,15 +509,15 @@ class Network(nn.Module):
                     chunks = [(rays8[i:i + per], None if order is None else order[i:i + per],
                                out if order is not None else tuple(t[i:i + per] for t in out)) for i in range(0, R, per)]
                     self._render_overlapped(chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                            wc['table'], pack, boxes)
+                                            wc['table'], pack, boxes, center)
                 for i in range(0, 0 if overlap else R, rays_per_pass):
                     n = min(rays_per_pass, R - i)
                     if order is not None:
                         self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                          wc['table'], out=out, out_rows=order[i:i + n], pack=pack, boxes=boxes)
+                                          wc['table'], out=out, out_rows=order[i:i + n], pack=pack, boxes=boxes, center=center)
                     else:
                         self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                          wc['table'], out=tuple(t[i:i + n] for t in out), pack=pack, boxes=boxes)
+                                          wc['table'], out=tuple(t[i:i + n] for t in out), pack=pack, boxes=boxes, center=center)
                 rgb, acc, depth = out
                 comp_loss = torch.zeros(1, device=dev)
         else:

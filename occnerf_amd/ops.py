@@ -427,10 +427,27 @@ def msknn(xyz, points, index_map, scale_begin, seed_from_coarser):
     return out
 
 
-def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser, mask=None, rows=None, count=None, out=None):
+def knn_center(c, points, index_map, scale_begin):
+    """c[3] (device) against the brute-force multi-scale layout (ops.msknn's points / index_map / scale_begin) ->
+    (center[4] = (c, r^2), idx[nscale, 10]): c's neighbours and the squared radius inside which every query provably has the same
+    neighbours in the same order (0: no such radius).  For msknn_clustered(center=...)."""
+    nscale = len(scale_begin) - 1
+    center = torch.empty(4, device=c.device, dtype=torch.float32)
+    idx = torch.empty(nscale, 10, device=c.device, dtype=torch.int32)
+    _kb, pb = _host_i32(scale_begin)
+    with _guard(c):
+        rc = _lib.lib().occnerf_knn_center(_chk(c, torch.float32, 'c'), _chk(points, torch.float32, 'points'),
+                                           _chk(index_map, torch.int32, 'index_map'), pb, nscale, center.data_ptr(), idx.data_ptr(),
+                                           _stream(c))
+    _lib.check(rc, 'knn_center')
+    return center, idx
+
+
+def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser, mask=None, rows=None, count=None, out=None, center=None):
     """cl: device-side cluster layout (dict, see Network._context / geometry.build_knn_clusters).
     mask[n_rays*S] (optional): samples with mask == 0 are skipped, their output rows left unwritten.
-    rows / count (optional, instead of mask): ascending int32 list of the samples to query and its length on the device."""
+    rows / count (optional, instead of mask): ascending int32 list of the samples to query and its length on the device.
+    center (optional): ops.knn_center's pair -- queries inside its radius take the cached indices (same results)."""
     nscale = int(cl['ranges'].shape[0]) + 1
     if out is None:
         out = torch.empty(n_rays * S, nscale, 10, device=xyz.device, dtype=torch.int32)
@@ -440,14 +457,16 @@ def msknn_clustered(xyz, n_rays, S, cl, seed_from_coarser, mask=None, rows=None,
     _kc, pc = _host_i32(cl['coarse_rows'])
     _ks, ps = _host_i32(seed_from_coarser)
     with _guard(xyz):
-        rc = _lib.lib().occnerf_msknn_clustered(
+        rc = _lib.lib().occnerf_msknn_clustered_centered(
             _chk(xyz, torch.float32, 'xyz'), _opt(mask, torch.float32, 'mask'), int(n_rays), int(S),
             _chk(cl['points'], torch.float32, 'points'), _chk(cl['centers'], torch.float32, 'centers'), _chk(cl['ranges'], torch.int32, 'cluster_ranges'),
             _chk(cl['radius'], torch.float32, 'cluster_radius'), int(cl['ncl']),
             _opt(cl.get('group_centers'), torch.float32, 'group_centers'), _opt(cl.get('group_ranges'), torch.int32, 'group_ranges'),
             _opt(cl.get('group_radius'), torch.float32, 'group_radius'), int(cl.get('ngrp', 0)), pc, ps, nscale,
             _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'),
-            None if ray_start is None else ray_start.data_ptr(), out.data_ptr(), _stream(xyz))
+            None if ray_start is None else ray_start.data_ptr(),
+            None if center is None else _chk(center[0], torch.float32, 'center'),
+            None if center is None else _chk(center[1], torch.int32, 'center_idx'), out.data_ptr(), _stream(xyz))
     _lib.check(rc, 'msknn_clustered')
     return out
 

@@ -457,6 +457,68 @@ def test_msknn_tie_suite(ops, seed):
     same(ops.knn_small(T(q), T(base), 3).cpu().numpy(), want[:, 0, :3], 'k = 3 kernel on the tie model')
 
 
+def test_knn_center_cache_is_exact(ops, oracle):
+    """Round 4: queries inside the radius ops.knn_center derives for a point c take c's cached neighbour lists instead of a
+    search.  (a) queries at 0 ... 0.999 r and 1.001 ... 100 r around several c (on the body, inside it, at the frame's collapse
+    point): clustered-with-cache == brute force == oracle, index for index, and the inside ones really equal c's lists;
+    (b) a c whose 11 nearest points tie (lattice cell centre of the tie model) gets r = 0;
+    (c) the benchmark frame rendered with the cache on and off: identical pixels, and the cache serves most of the queries."""
+    from occnerf_amd import geometry, synth
+    ctx = util.model_context(0, False)
+    m = _dev_model(ctx, ops)
+    cl = _clusters(ctx)
+    rng = np.random.RandomState(3)
+    base = ctx['point_base']
+    served = 0
+    for c in (np.array([-4.1e-5, -1.5e-5, -5.7e-6], np.float32), base[100] + np.float32(0.013), np.array([0.2, -0.3, 0.05], np.float32),
+              base[4000] * np.float32(0.5), np.array([0.0, 0.45, 0.02], np.float32)):
+        center, idx = ops.knn_center(T(c), m['points'], m['imap'], m['begin'])
+        r = float(center[3].sqrt())
+        assert torch.equal(center[:3].cpu(), torch.from_numpy(c))
+        want_c = oracle.msknn(c[None], base, ctx['fps'], k=10)[0]
+        same(idx.cpu().numpy(), want_c, 'centre lists')
+        if r == 0.0:
+            continue
+        assert 1e-7 < r < 1e-2
+        n_rays, S = 64, 8
+        dirs = rng.randn(n_rays * S, 3)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        rad = rng.choice([0.0, 0.3, 0.9, 0.999, 1.001, 1.5, 3.0, 100.0], n_rays * S)
+        q = (c[None].astype(np.float64) + dirs * (rad * r)[:, None]).astype(np.float32)
+        want = oracle.msknn(q, base, ctx['fps'], k=10)
+        brute = ops.msknn(T(q), m['points'], m['imap'], m['begin'], m['seed']).cpu().numpy()
+        same(brute, want, 'brute force near a centre')
+        for kw in ({}, {'mask': T((rng.rand(n_rays * S) < 0.7).astype(np.float32))}):
+            got = ops.msknn_clustered(T(q), n_rays, S, cl, [1, 1, 1, 0], center=(center, idx), **kw).cpu().numpy()
+            keep = np.ones(n_rays * S, bool) if not kw else kw['mask'].cpu().numpy() > 0
+            same(got[keep], want[keep], 'clustered kNN with the centre cache')
+        inside = np.linalg.norm(q.astype(np.float64) - c, axis=1) < 0.99 * r
+        assert inside.sum() > 100 and (want[inside] == want_c[None]).all()
+        served += int(inside.sum())
+    assert served > 300
+    tb, tsets, tq, twant = util.knn_tie_model()
+    rows, imap, begin = [], [], [0]
+    for ix in tsets:
+        pad = (-len(ix)) % 4
+        rows.append(np.concatenate([tb[ix], np.full((pad, 3), np.inf, np.float32)]))
+        imap.append(np.concatenate([ix, np.zeros(pad, ix.dtype)]))
+        begin.append(begin[-1] + len(ix) + pad)
+    p4 = np.concatenate(rows)
+    p4 = np.concatenate([p4, np.zeros((p4.shape[0], 1), np.float32)], 1)
+    cen, _ = ops.knn_center(T(np.array([2.5 / 8, 2.5 / 8, 2.5 / 8], np.float32)), T(p4), T(np.concatenate(imap).astype(np.int32)), begin)
+    assert float(cen[3]) == 0.0                                         # 8 equidistant corners: no radius
+    net, _ = build_network(seed=0, amplify=False, S=128, non_rigid=True)
+    data = frame_to_device(synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28), DEV)
+    outs = []
+    for on in (True, False):
+        net.cfg.knn_center_cache = on
+        with torch.no_grad():
+            o = net(**data, iter_val=1e7)
+        outs.append(torch.cat([o['rgb'], o['alpha'][:, None], o['depth'][:, None]], 1))
+    net.cfg.knn_center_cache = True
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_point_stage_bit_exact(case, ops, oracle):
     g, ctx, o = case
     m = _dev_model(ctx, ops)
