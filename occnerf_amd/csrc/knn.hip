@@ -215,57 +215,60 @@ __global__ __launch_bounds__(256) void knn_center_kernel(const float *__restrict
                                                          const int32_t *__restrict__ index_map, MsKnnScales sc,
                                                          float *__restrict__ center_out /*[4]: c, r^2*/,
                                                          int32_t *__restrict__ idx_out /*[nscale][10]*/) {
-    __shared__ float s_d[256];
-    __shared__ int s_r[256];
-    __shared__ float s_sel_d[11];
-    __shared__ int s_sel_r[11];
-    __shared__ float s_gap, s_dmax;
+    // One wave per scale (<= 4 scales, 4 waves), no block-wide rendezvous inside the search: a lane keeps the 11 smallest
+    // (distance, row) keys of its share of the scale's points in registers -- key = distance bits << 32 | row: for non-negative
+    // floats the unsigned order of the 64-bit patterns is the lexicographic order -- and the wave then pops the global minimum
+    // 11 times (a shuffle reduction; the owning lane advances its head).
+    __shared__ unsigned long long s_key[4][11];
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
     const float cx = c[0], cy = c[1], cz = c[2];
-    if (threadIdx.x == 0) s_gap = INFINITY, s_dmax = 0.0f;
-    __syncthreads();
-    for (int l = 0; l < sc.nscale; l++) {
+    if (l < sc.nscale) {
         const int jb = sc.begin[l], je = sc.end[l];
-        float last_d = -1.0f;
-        int last_r = -1;
+        unsigned long long best[11];
+#pragma unroll
+        for (int p = 0; p < 11; p++) best[p] = ~0ull;
+        for (int j = jb + lane; j < je; j += 64) {
+            const float4 P = points[j];
+            const float dx = cx - P.x, dy = cy - P.y, dz = cz - P.z;
+            const float d = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+            unsigned long long t = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(j - jb);
+            if (!(d < INFINITY)) t = ~0ull;                       // +inf pad rows (and NaN) never enter
+#pragma unroll
+            for (int p = 0; p < 11; p++) {                        // sorted insertion: carry the larger key down the list
+                const unsigned long long lo = t < best[p] ? t : best[p];
+                t = t < best[p] ? best[p] : t;
+                best[p] = lo;
+            }
+        }
         for (int round = 0; round < 11; round++) {
-            // smallest (distance, row) strictly above the last one taken
-            float bd = INFINITY;
-            int br = 0x7fffffff;
-            for (int j = jb + threadIdx.x; j < je; j += blockDim.x) {
-                const float4 P = points[j];
-                const float dx = cx - P.x, dy = cy - P.y, dz = cz - P.z;
-                const float d = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
-                const int row = j - jb;
-                const bool after = d > last_d || (d == last_d && row > last_r);
-                if (after && (d < bd || (d == bd && row < br))) bd = d, br = row;
+            unsigned long long m = best[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = ((unsigned long long)__shfl_xor((unsigned)(m >> 32), o) << 32) | __shfl_xor((unsigned)m, o);
+                m = other < m ? other : m;
             }
-            s_d[threadIdx.x] = bd, s_r[threadIdx.x] = br;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if ((int)threadIdx.x < o) {
-                    const float od = s_d[threadIdx.x + o];
-                    const int orow = s_r[threadIdx.x + o];
-                    if (od < s_d[threadIdx.x] || (od == s_d[threadIdx.x] && orow < s_r[threadIdx.x]))
-                        s_d[threadIdx.x] = od, s_r[threadIdx.x] = orow;
-                }
-                __syncthreads();
+            if (best[0] == m && m != ~0ull) {                     // (keys are unique: one owner) pop
+#pragma unroll
+                for (int p = 0; p < 10; p++) best[p] = best[p + 1];
+                best[10] = ~0ull;
             }
-            last_d = s_d[0], last_r = s_r[0];
-            if (threadIdx.x == 0) s_sel_d[round] = last_d, s_sel_r[round] = last_r;
-            __syncthreads();
+            if (lane == 0) s_key[l][round] = m;
         }
-        if (threadIdx.x == 0) {
-            float g = s_gap;
-            for (int j = 0; j < 10; j++) g = fminf(g, s_sel_d[j + 1] - s_sel_d[j]);      // (inf - x: a scale with < 11 real points...)
-            if (!(s_sel_d[10] < INFINITY)) g = 0.0f;                                    // ... disables the cache
-            s_gap = g;
-            s_dmax = fmaxf(s_dmax, s_sel_d[10] < INFINITY ? s_sel_d[10] : 0.0f);
-        }
-        if (threadIdx.x < 10) idx_out[l * 10 + threadIdx.x] = index_map[jb + s_sel_r[threadIdx.x]];
-        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x < sc.nscale * 10) {
+        const int ls = threadIdx.x / 10, j = threadIdx.x % 10;
+        idx_out[ls * 10 + j] = index_map[sc.begin[ls] + (int)(unsigned)s_key[ls][j]];
     }
     if (threadIdx.x == 0) {
-        const float r = 0.9f * (0.5f * s_gap - 2e-6f * (s_dmax + 1.0f));
+        float g = INFINITY, dmax = 0.0f;
+        for (int ls = 0; ls < sc.nscale; ls++) {
+            if (s_key[ls][10] == ~0ull) g = 0.0f;                  // a scale with < 11 real points: no radius
+            for (int j = 0; j < 10; j++)
+                g = fminf(g, __uint_as_float((unsigned)(s_key[ls][j + 1] >> 32)) - __uint_as_float((unsigned)(s_key[ls][j] >> 32)));
+            if (s_key[ls][10] != ~0ull) dmax = fmaxf(dmax, __uint_as_float((unsigned)(s_key[ls][10] >> 32)));
+        }
+        const float r = 0.9f * (0.5f * g - 2e-6f * (dmax + 1.0f));
         center_out[0] = cx, center_out[1] = cy, center_out[2] = cz;
         center_out[3] = (r > 0.0f && r < INFINITY) ? r * r : 0.0f;
     }
