@@ -305,6 +305,20 @@ int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs
                             const int32_t *geo_idxs, const float *att_in, const int32_t *rows,
                             const int32_t *n_dev, const float *point_geo, const float *point_tail, int32_t P,
                             float *mlp_in, float *raw, float *enc_in, void *stream);
+/* The renderer's form with the kNN centre cache (occnerf_knn_center): center[4] = (c, r^2) and center_agg[36] = columns 0..35
+ * of mlp_in of a sample that has c's neighbour lists (this function on a sample at c).  A group of 8 consecutive listed
+ * samples that all lie inside the radius -- they all carry c's 40 ids -- copies those columns instead of gathering the 40 rows.
+ * Same outputs, bit for bit.  Both pointers nullable together. */
+int occnerf_sample_features_centered(const float *xyz, int64_t N, const int32_t *knn_idxs, int32_t nscale,
+                            const float *point_base, const double *normals,
+                            const double *unit_normals, const float *counter,
+                            const float *table, float bound, float two_bound,
+                            const float *embeddings, const int32_t *offsets,
+                            const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
+                            const int32_t *geo_idxs, const float *att_in, const int32_t *rows,
+                            const int32_t *n_dev, const float *point_geo, const float *point_tail, int32_t P,
+                            const float *center, const float *center_agg,
+                                     float *mlp_in, float *raw, float *enc_in, void *stream);
 
 /* Differentiable neighbour aggregation of the training path (occnerf_mlp.py:86-126 simple_agg with the
  * gather of :176-178): agg[n,:] = sum_j atts[n,j] * feats[knn[n,j],:] for feats[P,F] (F <= 64), knn[N,K],

@@ -75,6 +75,9 @@ SIGNATURES = {
     'occnerf_sample_features': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp,
                                            _vp, _vp, _u32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
                                            _vp, _vp]),
+    'occnerf_sample_features_centered': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp,
+                                                    _vp, _vp, _u32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                                    _vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp_packed_floats': (_i64, []),
     'occnerf_canonical_mlp_pack': (C.c_int, [_vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),

@@ -399,8 +399,18 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
     const float4 *__restrict__ geo /*[P] 64-byte GeoRec*/, const float4 *__restrict__ tailc /*[P] (table cols 32..34, counter)*/,
     const float4 *__restrict__ table, const float2 *__restrict__ embeddings,
     LevelRecs levels, LevelRecs8 levels8, FeatParams prm, const int32_t *__restrict__ rows /*nullable: compact list of samples*/,
-    const int32_t *__restrict__ n_dev /*nullable: device-side count of rows*/, float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out) {
+    const int32_t *__restrict__ n_dev /*nullable: device-side count of rows*/, float *__restrict__ mlp_in, float *__restrict__ raw, float *__restrict__ enc_in_out,
+    const float *__restrict__ center /*nullable: occnerf_knn_center's [4] (c, r^2)*/,
+    const float *__restrict__ center_agg /*with center: columns 0..35 of mlp_in for a sample that has c's neighbour lists*/) {
     constexpr int NK = 4 * kKnn;                       // 40 neighbours over 4 scales
+    // CENTRE AGGREGATE (round 4).  The kNN kernel hands every query inside the centre cache's radius the SAME 40 neighbour ids
+    // (csrc/knn.hip: the samples that collapse onto the frame's point c, two thirds of the live ones), and columns 0..35 of
+    // mlp_in -- the visibility-softmax aggregate of those 40 table rows, its three tail columns and the variance -- are a
+    // function of the ids alone: for such a sample they are the 36 numbers the caller computed once for c (this kernel on a
+    // sample at c).  A trip whose samples ALL lie inside the radius (the same |p - c|^2 < r^2 test as the kNN kernel's)
+    // therefore skips the count / softmax / 40-row phase, 46 % of a trip, and copies them: same bits (tested).
+    float ccx = 0.f, ccy = 0.f, ccz = 0.f, cr2 = 0.f;
+    if (center) ccx = center[0], ccy = center[1], ccz = center[2], cr2 = center[3];
     // The texture path is this kernel's bound (TA busy 80-89 %, ~16 cycles per gather instruction of 8+ bytes per lane,
     // 64 when every lane has its own line): the five (tail, count) gathers per sample group -- 64 lines each -- are LDS
     // reads instead when the records of all points fit.
@@ -463,10 +473,21 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
         const int64_t o2 = out_row(it + 2);
         float *out = mlp_in + o * 68;
 
+        // every live sample of this trip inside the centre's radius: its columns 0..35 are the centre's (wave-uniform)
+        bool cached_agg = false;
+        if (cr2 > 0.0f) {
+            const float dx = cur.p[0] - ccx, dy = cur.p[1] - ccy, dz = cur.p[2] - ccz;
+            const bool inside = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) < cr2;
+            cached_agg = __builtin_amdgcn_ballot_w64(live && !inside) == 0;
+        }
         // (tail, count) of the lane's five rows: in flight with the point records
         float4 tl[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) tl[k] = LDS_TAIL ? s_tail[cur.id5[k]] : ld32(tailc, (uint32_t)cur.id5[k] * 16u);
+        for (int k = 0; k < 5; k++) tl[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!cached_agg) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) tl[k] = LDS_TAIL ? s_tail[cur.id5[k]] : ld32(tailc, (uint32_t)cur.id5[k] * 16u);
+        }
 
         // ---- neighbour geometry: the four lanes of a quad fetch one neighbour's 64-byte record together ----
         // A gather costs one L1 look-up per run of adjacent lanes on the same line (tools/gather_rate.hip), never
@@ -539,53 +560,56 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
         }
 
         // ---- visibility softmax: lane g owns neighbours 5g..5g+4 ----
-        float a5[5];
-        float lmin = INFINITY;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            a5[k] = tl[k].w;
-            lmin = fminf(lmin, a5[k]);
-        }
-        const float amin = grp_min8(lmin);
-        float lmax = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            a5[k] = __fadd_rn(a5[k], __fsub_rn(1.0f, amin));
-            lmax = fmaxf(lmax, a5[k]);
-        }
-        const float amax = grp_max8(lmax);
-        float lsum = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            a5[k] = __fdiv_rn(a5[k], amax);
-            lsum += a5[k];
-        }
-        const float mean = __fdiv_rn(grp_sum8(lsum), (float)NK);
-        float lvar = 0.0f, lsm = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const float dl = a5[k] - mean;
-            lvar += dl * dl;
-            lsm = fmaxf(lsm, a5[k]);
-        }
-        const float var = __fdiv_rn(grp_sum8(lvar), (float)(NK - 1));
-        const float smax = grp_max8(lsm);
-        float le = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            a5[k] = expf(__fsub_rn(a5[k], smax));
-            le += a5[k];
-        }
-        const float ssum = grp_sum8(le);
-#pragma unroll
-        for (int k = 0; k < 5; k++) a5[k] = __fdiv_rn(a5[k], ssum);
-
+        float a5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        float var = 0.0f;
         float tail[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            tail[0] += a5[k] * tl[k].x;
-            tail[1] += a5[k] * tl[k].y;
-            tail[2] += a5[k] * tl[k].z;
+        if (!cached_agg) {
+            float lmin = INFINITY;
+    #pragma unroll
+            for (int k = 0; k < 5; k++) {
+                a5[k] = tl[k].w;
+                lmin = fminf(lmin, a5[k]);
+            }
+            const float amin = grp_min8(lmin);
+            float lmax = -INFINITY;
+    #pragma unroll
+            for (int k = 0; k < 5; k++) {
+                a5[k] = __fadd_rn(a5[k], __fsub_rn(1.0f, amin));
+                lmax = fmaxf(lmax, a5[k]);
+            }
+            const float amax = grp_max8(lmax);
+            float lsum = 0.0f;
+    #pragma unroll
+            for (int k = 0; k < 5; k++) {
+                a5[k] = __fdiv_rn(a5[k], amax);
+                lsum += a5[k];
+            }
+            const float mean = __fdiv_rn(grp_sum8(lsum), (float)NK);
+            float lvar = 0.0f, lsm = -INFINITY;
+    #pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const float dl = a5[k] - mean;
+                lvar += dl * dl;
+                lsm = fmaxf(lsm, a5[k]);
+            }
+            var = __fdiv_rn(grp_sum8(lvar), (float)(NK - 1));
+            const float smax = grp_max8(lsm);
+            float le = 0.0f;
+    #pragma unroll
+            for (int k = 0; k < 5; k++) {
+                a5[k] = expf(__fsub_rn(a5[k], smax));
+                le += a5[k];
+            }
+            const float ssum = grp_sum8(le);
+    #pragma unroll
+            for (int k = 0; k < 5; k++) a5[k] = __fdiv_rn(a5[k], ssum);
+
+    #pragma unroll
+            for (int k = 0; k < 5; k++) {
+                tail[0] += a5[k] * tl[k].x;
+                tail[1] += a5[k] * tl[k].y;
+                tail[2] += a5[k] * tl[k].z;
+            }
         }
 
         // ---- hash encoding ----
@@ -635,42 +659,48 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
 
         // ---- gather the 40 rows: 128 B of encoding per row across the 8 lanes, one owner lane's five rows ahead ----
         float agg[4] = {0.f, 0.f, 0.f, 0.f};
-        // The table rows come in four chunks of ten (two owner lanes' rows); three chunks are in flight or in use at a
-        // time: with one chunk ahead every trip waited out most of an L2 round trip and the row phase was 46 % of the
-        // kernel (clock64 marks per phase).
-        const uint32_t piece = (uint32_t)g * 16u;
-        auto issue_chunk = [&](int c, float4 (&t)[10]) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-#pragma unroll
-                for (int k = 0; k < 5; k++)
-                    t[h * 5 + k] = ld32(table, (uint32_t)__shfl(cur.id5[k], 2 * c + h, 8) * (uint32_t)(kTableStride * 4) + piece);
-            }
-        };
-        float4 b0[10], b1[10], b2[10];
-        issue_chunk(0, b0);
-        issue_chunk(1, b1);
-#pragma unroll 1
-        for (int c = 0; c < 4; c++) {
-            const int cn = c + 2 < 4 ? c + 2 : 3;       // (the last two trips re-read chunk 3: L1 hits, no branch)
-            issue_chunk(cn, b2);
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const float w = __shfl(a5[k], 2 * c + h, 8);
-                    const float4 t = b0[h * 5 + k];
-                    agg[0] = __fadd_rn(agg[0], __fmul_rn(w, t.x));
-                    agg[1] = __fadd_rn(agg[1], __fmul_rn(w, t.y));
-                    agg[2] = __fadd_rn(agg[2], __fmul_rn(w, t.z));
-                    agg[3] = __fadd_rn(agg[3], __fmul_rn(w, t.w));
+        if (!cached_agg) {
+            // The table rows come in four chunks of ten (two owner lanes' rows); three chunks are in flight or in use at a
+            // time: with one chunk ahead every trip waited out most of an L2 round trip and the row phase was 46 % of the
+            // kernel (clock64 marks per phase).
+            const uint32_t piece = (uint32_t)g * 16u;
+            auto issue_chunk = [&](int c, float4 (&t)[10]) {
+    #pragma unroll
+                for (int h = 0; h < 2; h++) {
+    #pragma unroll
+                    for (int k = 0; k < 5; k++)
+                        t[h * 5 + k] = ld32(table, (uint32_t)__shfl(cur.id5[k], 2 * c + h, 8) * (uint32_t)(kTableStride * 4) + piece);
                 }
+            };
+            float4 b0[10], b1[10], b2[10];
+            issue_chunk(0, b0);
+            issue_chunk(1, b1);
+    #pragma unroll 1
+            for (int c = 0; c < 4; c++) {
+                const int cn = c + 2 < 4 ? c + 2 : 3;       // (the last two trips re-read chunk 3: L1 hits, no branch)
+                issue_chunk(cn, b2);
+    #pragma unroll
+                for (int h = 0; h < 2; h++) {
+    #pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const float w = __shfl(a5[k], 2 * c + h, 8);
+                        const float4 t = b0[h * 5 + k];
+                        agg[0] = __fadd_rn(agg[0], __fmul_rn(w, t.x));
+                        agg[1] = __fadd_rn(agg[1], __fmul_rn(w, t.y));
+                        agg[2] = __fadd_rn(agg[2], __fmul_rn(w, t.z));
+                        agg[3] = __fadd_rn(agg[3], __fmul_rn(w, t.w));
+                    }
+                }
+    #pragma unroll
+                for (int k = 0; k < 10; k++) b0[k] = b1[k], b1[k] = b2[k];
             }
-#pragma unroll
-            for (int k = 0; k < 10; k++) b0[k] = b1[k], b1[k] = b2[k];
+    #pragma unroll
+            for (int c = 0; c < 3; c++) tail[c] = grp_sum8(tail[c]);
+        } else {
+            const float4 ca = *reinterpret_cast<const float4 *>(center_agg + 4 * g);
+            agg[0] = ca.x, agg[1] = ca.y, agg[2] = ca.z, agg[3] = ca.w;
+            tail[0] = center_agg[32], tail[1] = center_agg[33], tail[2] = center_agg[34], var = center_agg[35];
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) tail[c] = grp_sum8(tail[c]);
         if (live) {
             *reinterpret_cast<float4 *>(out + 4 * g) = make_float4(agg[0], agg[1], agg[2], agg[3]);
             if (g == 0) *reinterpret_cast<float4 *>(out + 32) = make_float4(tail[0], tail[1], tail[2], var);
@@ -1110,7 +1140,24 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                                     const float *att_in, const int32_t *rows, const int32_t *n_dev,
                                     const float *point_geo, const float *point_tail, int32_t P,
                                     float *mlp_in, float *raw, float *enc_in, void *stream) {
+    return occnerf_sample_features_centered(xyz, N, knn_idxs, nscale, point_base, normals, unit_normals, counter, table, bound,
+                                            two_bound, embeddings, offsets, h_offsets, L, S, H, geo_idxs, att_in, rows, n_dev,
+                                            point_geo, point_tail, P, nullptr, nullptr, mlp_in, raw, enc_in, stream);
+}
+
+OCC_API int occnerf_sample_features_centered(const float *xyz, int64_t N, const int32_t *knn_idxs,
+                                             int32_t nscale, const float *point_base, const double *normals,
+                                             const double *unit_normals, const float *counter,
+                                             const float *table, float bound, float two_bound,
+                                             const float *embeddings, const int32_t *offsets,
+                                             const int32_t *h_offsets, uint32_t L, float S, uint32_t H,
+                                             const int32_t *geo_idxs,
+                                             const float *att_in, const int32_t *rows, const int32_t *n_dev,
+                                             const float *point_geo, const float *point_tail, int32_t P,
+                                             const float *center, const float *center_agg,
+                                             float *mlp_in, float *raw, float *enc_in, void *stream) {
     using namespace occ;
+    OCC_REQUIRE(!center == !center_agg, "sample_features: center and center_agg come together");
     if (N <= 0) return 0;
     OCC_REQUIRE(xyz && knn_idxs && point_base && normals && unit_normals && (counter || att_in) && table &&
                     embeddings && offsets && mlp_in && raw, "sample_features: null argument");
@@ -1174,9 +1221,10 @@ OCC_API int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *
                            N, knn_idxs, reinterpret_cast<const float4 *>(point_geo),
                            reinterpret_cast<const float4 *>(point_tail),
                            reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),
-                           levels, levels8, prm, rows, n_dev, mlp_in, raw, enc_in);
+                           levels, levels8, prm, rows, n_dev, mlp_in, raw, enc_in, center, center_agg);
         return check_launch("sample_features");
     }
+    OCC_REQUIRE(!center, "sample_features: the centre aggregate is only supported on the renderer's path");
     int64_t blocks = (N + 255) / 256;
     if (blocks > (int64_t)kNumCU * 16) blocks = (int64_t)kNumCU * 16;
     hipLaunchKernelGGL(sample_features_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, N,

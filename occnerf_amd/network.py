@@ -272,7 +272,8 @@ class Network(nn.Module):
             xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
             enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution,
-            rows=frows, count=fcount, pack=pack)
+            rows=frows, count=fcount, pack=pack, center=None if center is None else center[0],
+            center_agg=None if center is None else center[2])
         del knn
         if dedup:
             scan_b, mrows, mcount, _ = ops.repeat_heads(mlp_in, 68, fcount)
@@ -305,7 +306,7 @@ class Network(nn.Module):
         st['mlp_in'] = None
         return ops.composite(raw, st['mask'], st['z'], st['rays8'], bgcolor, out=out, out_rows=out_rows)[:3]
 
-    def _knn_center(self, cond, hann):
+    def _knn_center(self, cond, hann, table, pack):
         """(center, idx) of ops.knn_center for this frame's collapse point: wherever a sample's motion-weight sum is far below
         the 1e-4 clamp of the reference's warp (network.py:388) its warped position lands within a micrometre of the origin,
         hence -- after the non-rigid offset -- of offset(0): two thirds of a frame's live samples.  The kNN kernel hands those
@@ -314,7 +315,15 @@ class Network(nn.Module):
         c = torch.zeros(64, 3, device=self.point_base.device)
         if not self.cfg.ignore_non_rigid_motions:
             c = ops.nonrigid(c, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
-        return ops.knn_center(c[0].contiguous(), ctx['points'], ctx['index_map'], ctx['scale_begin'])
+        center, idx = ops.knn_center(c[0].contiguous(), ctx['points'], ctx['index_map'], ctx['scale_begin'])
+        # ... and the 36 leading feature columns every sample with c's neighbour lists has (functions of the 40 ids, the
+        # visibility counts and the per-point table alone): the feature kernel on samples at c
+        enc = self.cnl_mlp.module.encoder
+        row, _, _ = ops.sample_features(
+            c[:8].contiguous(), idx[None].expand(8, -1, -1).contiguous(), self.point_base.detach(), ctx['normals'], ctx['unit'],
+            self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'], enc.embeddings.detach(), enc.offsets,
+            enc.log2_per_level_scale, enc.base_resolution, pack=pack)
+        return center, idx, row[0, :36].contiguous()
 
     def _side_stream(self, dev):
         """The producer stream of the overlapped render (high priority: its small VALU / texture-path workgroups take the
@@ -490,7 +499,7 @@ class Network(nn.Module):
                 boxes = ops.bone_boxes(vol, Rs.shape[0]) if cfg.get('warp_bone_culling', True) else None
                 cond = f32(dst_posevec).reshape(-1) if iter_val >= nr.kick_in_iter else \
                     torch.zeros(dst_posevec.numel(), device=dev)
-                center = self._knn_center(cond, hann.tolist()) if cfg.get('knn_center_cache', True) and cfg.get('knn_culling', True) else None
+                center = self._knn_center(cond, hann.tolist(), wc['table'], pack) if cfg.get('knn_center_cache', True) and cfg.get('knn_culling', True) else None
                 rays_f = f32(torch.stack([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)]) if not torch.is_tensor(rays) else
                              rays.reshape(2, -1, 3))
                 order = morton_order(rays_f[1])

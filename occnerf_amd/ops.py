@@ -538,8 +538,10 @@ def point_pack(point_base, normals, unit, counter, table):
 
 def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bound32, two_bound32,
                     embeddings, offsets, S, H, raw=None, want_enc_in=False, geo_idxs=None,
-                    att_in=None, rows=None, count=None, pack=None):
+                    att_in=None, rows=None, count=None, pack=None, center=None, center_agg=None):
     """rows (int32[M], optional): compact list of samples to evaluate; outputs then have M rows.
+    center / center_agg (optional, renderer's path): ops.knn_center's [4] and the 36 leading columns of mlp_in of a sample
+    with the centre's neighbour lists -- groups of samples inside the radius copy them instead of gathering rows (same bits).
     count (int32[1] on the device, optional, with rows): the list's real length; M is then a capacity.
     pack: point_pack(...) of the same per-point inputs (built here when the renderer's kernel applies and the caller
     did not cache it)."""
@@ -555,7 +557,7 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
     raw = torch.empty(N, 5, device=dev, dtype=torch.float32) if raw is None else raw
     enc_in = torch.empty(N, 4, device=dev, dtype=torch.float32) if want_enc_in else None
     with _guard_dev(dev):
-        rc = _lib.lib().occnerf_sample_features(
+        rc = _lib.lib().occnerf_sample_features_centered(
             _chk(xyz, torch.float32, 'xyz'), N, _chk(knn_idxs, torch.int32, 'knn_idxs'),
             int(knn_idxs.shape[1]), _chk(point_base, torch.float32, 'point_base'),
             _chk(normals, torch.float64, 'normals'), _chk(unit, torch.float64, 'unit_normals'),
@@ -566,6 +568,7 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
             _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'),
             _opt(geo, torch.float32, 'point_geo'), _opt(tail, torch.float32, 'point_tail'),
             0 if geo is None else int(geo.shape[0]),
+            _opt(center, torch.float32, 'center'), _opt(center_agg, torch.float32, 'center_agg'),
             mlp_in.data_ptr(), _chk(raw, torch.float32, 'raw'),
             None if enc_in is None else enc_in.data_ptr(), _stream(xyz))
     _lib.check(rc, 'sample_features')

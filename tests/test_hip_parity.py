@@ -457,6 +457,12 @@ def test_msknn_tie_suite(ops, seed):
     same(ops.knn_small(T(q), T(base), 3).cpu().numpy(), want[:, 0, :3], 'k = 3 kernel on the tie model')
 
 
+def stagewise_table(ctx, oracle):
+    """The per-point feature table [P,35] of a model context (oracle side)."""
+    kb, sdf = oracle.point_sdf(ctx['point_cloud'], ctx['point_base'], ctx['normals'])
+    return oracle.point_table(kb, sdf, ctx['point_cloud'], ctx['bound'], ctx['embeddings'], ctx['offsets'], ctx['S'], ctx['H'])
+
+
 def test_knn_center_cache_is_exact(ops, oracle):
     """Round 4: queries inside the radius ops.knn_center derives for a point c take c's cached neighbour lists instead of a
     search.  (a) queries at 0 ... 0.999 r and 1.001 ... 100 r around several c (on the body, inside it, at the frame's collapse
@@ -507,6 +513,25 @@ def test_knn_center_cache_is_exact(ops, oracle):
     p4 = np.concatenate([p4, np.zeros((p4.shape[0], 1), np.float32)], 1)
     cen, _ = ops.knn_center(T(np.array([2.5 / 8, 2.5 / 8, 2.5 / 8], np.float32)), T(p4), T(np.concatenate(imap).astype(np.int32)), begin)
     assert float(cen[3]) == 0.0                                         # 8 equidistant corners: no radius
+    # (d) the feature kernel's cached aggregate: samples inside the radius -- whole groups of 8 and mixed groups -- with and
+    # without the centre: mlp_in and the signed distance bit for bit
+    c = np.array([-4.1e-5, -1.5e-5, -5.7e-6], np.float32)
+    center, idx = ops.knn_center(T(c), m['points'], m['imap'], m['begin'])
+    r = float(center[3].sqrt())
+    n_rays, S = 96, 16
+    off = rng.randn(n_rays * S, 3) * (0.2 * r)
+    far = rng.rand(n_rays * S) < 0.15
+    far[:320] = False                                                       # 40 whole groups of 8 inside
+    off[far] = rng.randn(int(far.sum()), 3) * 0.05
+    q = T((c[None].astype(np.float64) + off).astype(np.float32))
+    knn = ops.msknn_clustered(q, n_rays, S, cl, [1, 1, 1, 0], center=(center, idx))
+    table = T(np.concatenate([stagewise_table(ctx, oracle), np.zeros((len(base), ops.table_stride() - 35), np.float32)], 1))
+    args = (m['base'], m['normals'], m['unit'], T(ctx['counter']), table, m['b32'], m['tb32'], m['emb'], m['off'], ctx['S'], ctx['H'])
+    row = ops.sample_features(T(np.tile(c, (8, 1))), idx[None].expand(8, -1, -1).contiguous(), *args)[0][0, :36].contiguous()
+    plain = ops.sample_features(q, knn, *args)
+    fast = ops.sample_features(q, knn, *args, center=center, center_agg=row)
+    assert torch.equal(plain[0].view(torch.int32), fast[0].view(torch.int32)) and torch.equal(plain[1][:, 4], fast[1][:, 4])
+    assert torch.equal(plain[0][:320, :36], row[None].expand(320, -1))      # the inside samples do carry the centre's columns
     net, _ = build_network(seed=0, amplify=False, S=128, non_rigid=True)
     data = frame_to_device(synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28), DEV)
     outs = []
