@@ -314,7 +314,10 @@ class Network(nn.Module):
         ctx, pk = self._context(), self._packed_weights()
         c = torch.zeros(64, 3, device=self.point_base.device)
         if not self.cfg.ignore_non_rigid_motions:
-            c = ops.nonrigid(c, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
+            # (any point near the cluster serves as c -- the radius is proven for whatever c is searched -- so the first-version
+            # kernel's offset(0), equal to the LDS-staged kernel's to fp32 rounding, does; it keeps the per-kernel profiles of the
+            # frame's one big nr16 launch clean)
+            c = ops.nonrigid(c, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], direct=True)
         center, idx = ops.knn_center(c[0].contiguous(), ctx['points'], ctx['index_map'], ctx['scale_begin'])
         # ... and the 36 leading feature columns every sample with c's neighbour lists has (functions of the 40 ids, the
         # visibility counts and the per-point table alone): the feature kernel on samples at c
