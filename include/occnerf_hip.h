@@ -305,10 +305,11 @@ int occnerf_sample_features(const float *xyz, int64_t N, const int32_t *knn_idxs
                             const int32_t *geo_idxs, const float *att_in, const int32_t *rows,
                             const int32_t *n_dev, const float *point_geo, const float *point_tail, int32_t P,
                             float *mlp_in, float *raw, float *enc_in, void *stream);
-/* The renderer's form with the kNN centre cache (occnerf_knn_center): center[4] = (c, r^2) and center_agg[36] = columns 0..35
- * of mlp_in of a sample that has c's neighbour lists (this function on a sample at c).  A group of 8 consecutive listed
- * samples that all lie inside the radius -- they all carry c's 40 ids -- copies those columns instead of gathering the 40 rows.
- * Same outputs, bit for bit.  Both pointers nullable together. */
+/* The renderer's form with the kNN centre cache (occnerf_knn_center): center[4] = (c, r^2) and center_agg[72] = of a sample that
+ * has c's neighbour lists (this function on a sample at c) columns 0..35 of mlp_in, the encoder input x[4] (enc_in), columns
+ * 36..67 of mlp_in.  A group of 8 consecutive listed samples that all lie inside the radius -- they all carry c's 40 ids --
+ * copies columns 0..35 instead of gathering the 40 rows, and columns 36..67 as well when every one of its encoder inputs equals
+ * the centre's bit for bit.  Same outputs, bit for bit.  Both pointers nullable together. */
 int occnerf_sample_features_centered(const float *xyz, int64_t N, const int32_t *knn_idxs, int32_t nscale,
                             const float *point_base, const double *normals,
                             const double *unit_normals, const float *counter,

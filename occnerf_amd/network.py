@@ -322,11 +322,11 @@ class Network(nn.Module):
         # ... and the 36 leading feature columns every sample with c's neighbour lists has (functions of the 40 ids, the
         # visibility counts and the per-point table alone): the feature kernel on samples at c
         enc = self.cnl_mlp.module.encoder
-        row, _, _ = ops.sample_features(
+        row, _, enc_in = ops.sample_features(
             c[:8].contiguous(), idx[None].expand(8, -1, -1).contiguous(), self.point_base.detach(), ctx['normals'], ctx['unit'],
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'], enc.embeddings.detach(), enc.offsets,
-            enc.log2_per_level_scale, enc.base_resolution, pack=pack)
-        return center, idx, row[0, :36].contiguous()
+            enc.log2_per_level_scale, enc.base_resolution, pack=pack, want_enc_in=True)
+        return center, idx, ops.center_row(row[0], enc_in[0])
 
     def _side_stream(self, dev):
         """The producer stream of the overlapped render (high priority: its small VALU / texture-path workgroups take the

@@ -536,12 +536,19 @@ def point_pack(point_base, normals, unit, counter, table):
     return geo, tail
 
 
+def center_row(mlp_in_row, enc_in_row):
+    """The 72 floats sample_features(center_agg=...) takes: [columns 0..35 of the centre sample's mlp_in | its encoder input x[4] |
+    its columns 36..67 (the 32 encoded features of x)]."""
+    return torch.cat([mlp_in_row[:36], enc_in_row[:4], mlp_in_row[36:68]]).contiguous()
+
+
 def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bound32, two_bound32,
                     embeddings, offsets, S, H, raw=None, want_enc_in=False, geo_idxs=None,
                     att_in=None, rows=None, count=None, pack=None, center=None, center_agg=None):
     """rows (int32[M], optional): compact list of samples to evaluate; outputs then have M rows.
-    center / center_agg (optional, renderer's path): ops.knn_center's [4] and the 36 leading columns of mlp_in of a sample
-    with the centre's neighbour lists -- groups of samples inside the radius copy them instead of gathering rows (same bits).
+    center / center_agg (optional, renderer's path): ops.knn_center's [4] and ops.center_row of a sample with the centre's
+    neighbour lists -- groups of samples inside the radius copy its aggregate columns instead of gathering rows, and its encoded
+    columns too when their encoder input is bitwise the centre's (same bits).
     count (int32[1] on the device, optional, with rows): the list's real length; M is then a capacity.
     pack: point_pack(...) of the same per-point inputs (built here when the renderer's kernel applies and the caller
     did not cache it)."""

@@ -520,6 +520,7 @@ def test_knn_center_cache_is_exact(ops, oracle):
     r = float(center[3].sqrt())
     n_rays, S = 96, 16
     off = rng.randn(n_rays * S, 3) * (0.2 * r)
+    off[:160] = rng.randn(160, 3) * 1e-10                                   # 20 whole groups as close to c as the frame's collapsed samples
     far = rng.rand(n_rays * S) < 0.15
     far[:320] = False                                                       # 40 whole groups of 8 inside
     off[far] = rng.randn(int(far.sum()), 3) * 0.05
@@ -527,11 +528,18 @@ def test_knn_center_cache_is_exact(ops, oracle):
     knn = ops.msknn_clustered(q, n_rays, S, cl, [1, 1, 1, 0], center=(center, idx))
     table = T(np.concatenate([stagewise_table(ctx, oracle), np.zeros((len(base), ops.table_stride() - 35), np.float32)], 1))
     args = (m['base'], m['normals'], m['unit'], T(ctx['counter']), table, m['b32'], m['tb32'], m['emb'], m['off'], ctx['S'], ctx['H'])
-    row = ops.sample_features(T(np.tile(c, (8, 1))), idx[None].expand(8, -1, -1).contiguous(), *args)[0][0, :36].contiguous()
-    plain = ops.sample_features(q, knn, *args)
-    fast = ops.sample_features(q, knn, *args, center=center, center_agg=row)
+    cm, _, ce = ops.sample_features(T(np.tile(c, (8, 1))), idx[None].expand(8, -1, -1).contiguous(), *args, want_enc_in=True)
+    row = ops.center_row(cm[0], ce[0])
+    assert row.shape == (72,)
+    plain = ops.sample_features(q, knn, *args, want_enc_in=True)
+    fast = ops.sample_features(q, knn, *args, center=center, center_agg=row, want_enc_in=True)
     assert torch.equal(plain[0].view(torch.int32), fast[0].view(torch.int32)) and torch.equal(plain[1][:, 4], fast[1][:, 4])
-    assert torch.equal(plain[0][:320, :36], row[None].expand(320, -1))      # the inside samples do carry the centre's columns
+    assert torch.equal(plain[2].view(torch.int32), fast[2].view(torch.int32))
+    assert torch.equal(plain[0][:320, :36], row[None, :36].expand(320, -1))      # the inside samples do carry the centre's columns
+    # ... and most of them the centre's encoder input, hence its encoded columns (the rest differ in the last bit of x and
+    # are encoded as usual)
+    same_x = (plain[2][:320].view(torch.int32) == row[36:40].view(torch.int32)).all(1)
+    assert float(same_x[:160].float().mean()) > 0.5 and torch.equal(plain[0][:320][same_x][:, 36:], row[None, 40:].expand(int(same_x.sum()), -1))
     net, _ = build_network(seed=0, amplify=False, S=128, non_rigid=True)
     data = frame_to_device(synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28), DEV)
     outs = []
