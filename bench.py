@@ -36,7 +36,9 @@ step (forward + backward + clip + Adam, all HIP kernels) on 6 144 rays x 128 sam
 192-sample frame with seeded visibility counts, renderer default and every-live-sample.  `movement` (N = 1): BASELINE
 configs[2]'s sequence on one GPU through the loop run.py executes (occnerf_amd/sequence.py: device ray generation, named
 camera, one frame of lag, device image assembly, uint8 D2H), rays/s over a whole pass.  With N > 1 `config.per_rank_rays` /
-`per_rank_live_samples` show the balance of the shard plan.  `rccl_world1` (N = 1): the same frame through the N > 1
+`per_rank_live_samples` show the balance of the shard plan.  `no_shortcuts` (N = 1): the frame with round 4's two exact
+data-dependent shortcuts off (cfg.knn_center_cache, cfg.warp_bone_culling) -- identical pixels, the way round 3 rendered it.
+`rccl_world1` (N = 1): the same frame through the N > 1
 branch of the sharded renderer with a ONE-rank `nccl` process group (plan + checksum all-gather, padded send buffer,
 asynchronous dist.gather on device buffers, work.wait(), un-permutation): what a single-GPU box can execute of the
 multi-GPU path; pixels bit-identical to the headline's, never part of `value`.  It runs in a CHILD process under a time limit
@@ -315,7 +317,7 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the side measurements (bf16x3, all samples, train)')
     ap.add_argument('--rccl-inline', action='store_true', help=argparse.SUPPRESS)      # (the child process of the rccl_world1 leg)
     ap.add_argument('--only', default=None, help='comma-separated side legs to run beside the headline (default: all): '
-                                                 'dedup,rccl_world1,alt,all_samples,train,movement,config4,overlap')
+                                                 'dedup,rccl_world1,alt,no_shortcuts,all_samples,train,movement,config4')
     args = ap.parse_args()
     only = None if args.only is None else set(args.only.split(','))
 
@@ -463,6 +465,18 @@ def main():
                                        'ms_per_step': dtb / args.steps * 1e3}}
             net.cfg.mlp_precision = 'fp32'
             net.invalidate_cache()
+        if leg('no_shortcuts'):
+            # the two exact data-dependent shortcuts of round 4 off (kNN / feature centre cache, warp bone culling): the same frame
+            # the way round 3 rendered it -- identical pixels
+            net.cfg.knn_center_cache, net.cfg.warp_bone_culling = False, False
+            dtn, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
+            net.cfg.knn_center_cache, net.cfg.warp_bone_culling = True, True
+            side['no_shortcuts'] = {
+                'knn_center_cache': False, 'warp_bone_culling': False, 'value': R * args.steps / dtn, 'unit': 'rays/s',
+                'ms_per_step': dtn / args.steps * 1e3,
+                'note': 'the headline serves the kNN queries (and their feature aggregate) that lie within a proven radius of the '
+                        'frame\'s collapse point from ONE search, and skips bones whose weight channel cannot reach a wave\'s samples; '
+                        'both exact (bit-identical pixels, tested); every live sample still goes through both MLPs'}
         if leg('all_samples'):
             # every sample evaluated (cfg.skip_empty_samples off): same pixels bit for bit
             net.cfg.skip_empty_samples = False
@@ -518,6 +532,8 @@ def main():
                        'samples_evaluated_per_launch': float(np.mean(nsmp)),
                        'skip_empty_samples': bool(net.cfg.get('skip_empty_samples', True)),
                        'dedup_repeated_samples': False,
+                       'knn_center_cache': bool(net.cfg.get('knn_center_cache', True)),
+                       'warp_bone_culling': bool(net.cfg.get('warp_bone_culling', True)),
                        'world_size_formed': formed_world, 'backend': backend if world > 1 else None,
                        'per_rank_rays': [p[0] for p in per_rank],
                        'per_rank_live_samples': [p[1] for p in per_rank],
