@@ -36,6 +36,13 @@ extern "C" {
 int occnerf_abi_version(void);
 const char *occnerf_last_error(void);
 
+/* Experiment knobs: kernel variants that were measured and not shipped stay selectable for A/B runs.  Each knob
+ * is read from its environment variable once, at first use, and clamped to its valid range; this call reads (value < 0) or
+ * sets it afterwards.  Names: "cohab_lds" (OCCNERF_COHAB_LDS, bytes of padding LDS, 0..131072), "features_small"
+ * (OCCNERF_FEATURES_SMALL, 0/1), "features_rowcache" (OCCNERF_FEATURES_ROWCACHE, 0/1).  Returns the previous value, -1 for an
+ * unknown name.  No counterpart in the reference. */
+int occnerf_experiment_knob(const char *name, int value);
+
 /* ------------------------------------------------------------------------------------
  * 1. Grid encoder -- replaces core/nets/occnerf/gridencoder/src/bindings.cpp:5-9
  *    (prototypes gridencoder.h:12-15, kernels gridencoder.cu:87-369,506-645).

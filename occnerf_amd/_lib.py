@@ -18,6 +18,7 @@ _vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_
 SIGNATURES = {
     'occnerf_abi_version': (C.c_int, []),
     'occnerf_last_error': (C.c_char_p, []),
+    'occnerf_experiment_knob': (C.c_int, [C.c_char_p, C.c_int]),
     'occnerf_grid_encode_forward': (C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32,
                                                _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grid_encode_backward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,

@@ -29,6 +29,12 @@ inline int check_launch(const char *what) {
     return 0;
 }
 
+// Experiment knobs (A/B variants that were measured and NOT shipped).  Each is read from its environment
+// variable ONCE (first use), validated and clamped there, and can be switched at run time through the exported
+// occnerf_experiment_knob() -- launches never call getenv / atoi.
+enum Knob : int { kKnobCohabLds = 0, kKnobFeaturesSmall = 1, kKnobFeaturesRowcache = 2, kKnobCount = 3 };
+int knob(Knob k);
+
 #define OCC_REQUIRE(cond, ...)         \
     do {                               \
         if (!(cond)) {                 \

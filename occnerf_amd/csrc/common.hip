@@ -1,8 +1,10 @@
 // Library-wide host helpers: error reporting, ABI version, grid level constants.
 #include "common.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 
 namespace occ {
 
@@ -13,6 +15,32 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- experiment knobs ----------------------------------------------------------------------------------------------
+struct KnobSpec {
+    const char *name, *env;
+    int lo, hi;
+};
+// cohab_lds: bytes of unused dynamic LDS that pad a kNN / feature workgroup (the co-residency experiment of round 4);
+// at most what a gfx950 workgroup can still ask for beside those kernels' static LDS.
+static const KnobSpec kKnobSpecs[kKnobCount] = {{"cohab_lds", "OCCNERF_COHAB_LDS", 0, 128 * 1024},
+                                                {"features_small", "OCCNERF_FEATURES_SMALL", 0, 1},
+                                                {"features_rowcache", "OCCNERF_FEATURES_ROWCACHE", 0, 1}};
+static std::atomic<int> g_knob[kKnobCount];
+static std::atomic<bool> g_knob_read[kKnobCount];
+
+static int clamp_knob(int k, long v) {
+    return (int)(v < kKnobSpecs[k].lo ? kKnobSpecs[k].lo : (v > kKnobSpecs[k].hi ? kKnobSpecs[k].hi : v));
+}
+
+int knob(Knob k) {
+    if (!g_knob_read[k].load(std::memory_order_acquire)) {
+        const char *e = getenv(kKnobSpecs[k].env);
+        g_knob[k].store(e ? clamp_knob(k, strtol(e, nullptr, 10)) : 0);
+        g_knob_read[k].store(true, std::memory_order_release);
+    }
+    return g_knob[k].load(std::memory_order_relaxed);
 }
 
 // gridencoder.cu:137-139: scale = exp2f(level * S) * H - 1 (one fma, as nvcc contracts it),
@@ -56,3 +84,15 @@ GridModes4 make_grid_modes_d4(uint32_t L, const GridLevels &lv, const uint32_t *
 
 OCC_API int occnerf_abi_version(void) { return OCCNERF_ABI_VERSION; }
 OCC_API const char *occnerf_last_error(void) { return occ::g_err; }
+
+OCC_API int occnerf_experiment_knob(const char *name, int value) {
+    for (int k = 0; k < occ::kKnobCount; k++) {
+        if (name && strcmp(name, occ::kKnobSpecs[k].name) == 0) {
+            const int prev = occ::knob((occ::Knob)k);
+            if (value >= 0) occ::g_knob[k].store(occ::clamp_knob(k, value));
+            return prev;
+        }
+    }
+    occ::set_error("occnerf_experiment_knob: unknown knob '%s'", name ? name : "(null)");
+    return -1;
+}

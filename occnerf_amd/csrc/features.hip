@@ -421,6 +421,8 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
     // encoding piece now waits in a lane-private LDS slot (no registers held across the row phase) and the three stores
     // leave back to back at the end of the trip.
     __shared__ float4 s_out[LDS_TAIL ? 768 : 256];
+    static_assert(sizeof(float4) * (size_t)kLdsTailPoints + sizeof(float4) * 768 <= 160 * 1024,
+                  "sample_features8_kernel<LDS_TAIL>: (tail, count) image + per-lane encoding slots exceed gfx950's 160 KiB of LDS");
     if constexpr (LDS_TAIL) {
         for (int i = threadIdx.x; i < prm.P; i += blockDim.x) s_tail[i] = tailc[i];
         __syncthreads();
@@ -1206,17 +1208,15 @@ OCC_API int occnerf_sample_features_centered(const float *xyz, int64_t N, const 
                                      dense ? r1 * r1 * r1 : 3674653429u, 0u};
         }
         OCC_REQUIRE(P > 0, "sample_features: P=%d rows of packed point records", P);
-        const char *small_env = getenv("OCCNERF_FEATURES_SMALL");      // experiment: 4-wave workgroups, counts from L2
-        const bool force_small = small_env && small_env[0] == '1';
-        const bool lds_tail = P <= kLdsTailPoints && N >= 96 * 64 && !force_small;      // (small calls: not worth a 110 KiB image per block)
+        const bool force_small = knob(kKnobFeaturesSmall) != 0;      // experiment: 4-wave workgroups, counts from L2
+        const bool lds_tail = P <= kLdsTailPoints && N >= 96 * 64 && !force_small;      // (small calls: not worth a block-wide LDS image -- kLdsTailPoints x 16 B of (tail, count) records + 12 KiB of encoding slots, 156 of 160 KiB)
         const int threads = lds_tail ? 768 : 256;
         int64_t blocks8 = (N * 8 + threads - 1) / threads;
         const int64_t cap = lds_tail ? (int64_t)kNumCU : (int64_t)kNumCU * 32;
         if (blocks8 > cap) blocks8 = cap;
         // row cache (sample_features8r_kernel): opt-in with OCCNERF_FEATURES_ROWCACHE=1 -- bit-identical, measured slower
         // (see the kernel's header)
-        const char *rc_env = getenv("OCCNERF_FEATURES_ROWCACHE");
-        const bool rowcache_on = rc_env && rc_env[0] == '1';
+        const bool rowcache_on = knob(kKnobFeaturesRowcache) != 0;
         if (lds_tail && rowcache_on && P <= kCountPoints) {
             auto kr = generic ? sample_features8r_kernel<true> : sample_features8r_kernel<false>;
             hipLaunchKernelGGL(kr, dim3((unsigned)blocks8), dim3(kRowWaves * 64), 0, as_stream(stream), xyz, N, knn_idxs,
@@ -1227,8 +1227,7 @@ OCC_API int occnerf_sample_features_centered(const float *xyz, int64_t N, const 
         }
         auto kern = generic ? (lds_tail ? sample_features8_kernel<true, true> : sample_features8_kernel<true, false>)
                             : (lds_tail ? sample_features8_kernel<false, true> : sample_features8_kernel<false, false>);
-        const char *cohab_env = getenv("OCCNERF_COHAB_LDS");       // experiment, see msknn_clustered
-        const unsigned cohab_lds = (cohab_env && !lds_tail) ? (unsigned)atoi(cohab_env) : 0u;
+        const unsigned cohab_lds = lds_tail ? 0u : (unsigned)knob(kKnobCohabLds);       // experiment, see msknn_clustered
         if (cohab_lds) {
             if (blocks8 > (int64_t)kNumCU) blocks8 = kNumCU;
             OCC_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

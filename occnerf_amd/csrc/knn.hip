@@ -681,8 +681,7 @@ OCC_API int occnerf_msknn_clustered_centered(const float *xyz, const float *mask
     if (blocks > (int64_t)kNumCU * 3) blocks = (int64_t)kNumCU * 3;      // 12 resident waves per CU at this register count
     // experiment (OCCNERF_COHAB_LDS=<bytes>): one workgroup per CU, padded with unused LDS so that a CU holds at most one of
     // them and exactly one canonical-MLP workgroup (78 112 B) beside it
-    const char *cohab_env = getenv("OCCNERF_COHAB_LDS");
-    const unsigned cohab_lds = cohab_env ? (unsigned)atoi(cohab_env) : 0u;
+    const unsigned cohab_lds = (unsigned)knob(kKnobCohabLds);      // read once, clamped (common.hip)
     if (cohab_lds) {
         if (blocks > (int64_t)kNumCU) blocks = kNumCU;
         OCC_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(msknn_clustered_kernel),

@@ -268,6 +268,9 @@ class Network(nn.Module):
             knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], rows=frows, count=fcount, center=center)
         else:
             knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], mask=kmask, center=center)
+        if center is not None and len(center) > 3 and center[3] != self._center_stamp(table):
+            raise RuntimeError('stale kNN centre: its cached feature row was computed from another table / counter / embedding '
+                               'version than this frame\'s (ops.sample_features freshness contract)')
         mlp_in, raw_c, _ = ops.sample_features(
             xyz, knn, self.point_base.detach(), ctx['normals'], ctx['unit'],
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'],
@@ -326,7 +329,11 @@ class Network(nn.Module):
             c[:8].contiguous(), idx[None].expand(8, -1, -1).contiguous(), self.point_base.detach(), ctx['normals'], ctx['unit'],
             self.point_counter.detach(), table, ctx['bound32'], ctx['two_bound32'], enc.embeddings.detach(), enc.offsets,
             enc.log2_per_level_scale, enc.base_resolution, pack=pack, want_enc_in=True)
-        return center, idx, ops.center_row(row[0], enc_in[0])
+        # (the 4th entry pins what the cached row was computed from: ops.sample_features' freshness contract)
+        return center, idx, ops.center_row(row[0], enc_in[0]), self._center_stamp(table)
+
+    def _center_stamp(self, table):
+        return (table.data_ptr(), table._version, self.point_counter._version, self.cnl_mlp.module.encoder.embeddings._version)
 
     def _side_stream(self, dev):
         """The producer stream of the overlapped render (high priority: its small VALU / texture-path workgroups take the
@@ -440,6 +447,17 @@ class Network(nn.Module):
                                         self._host3(kwargs['cnl_bbox_scale_xyz']), boxes=boxes)
         return (mask.view(-1, S) != 0).sum(dim=1)
 
+    @torch.no_grad()
+    def render_preamble(self, data, iter_val=1e7):
+        """(Rs[24,3,3], Ts[24,3], vol[25,G,G,G]) of a frame exactly as the render branch of `forward` computes them (the fused
+        kernels of csrc/preamble.hip) -- for parity tools that feed a checker the same per-frame outputs."""
+        f32 = lambda t: t.detach().float().contiguous().to(self.point_base.device)          # noqa: E731
+        wc = self._weight_constants()
+        refine = iter_val >= self.cfg.pose_decoder.get('kick_in_iter', 0)
+        Rs, Ts = ops.pose_motion_bases(self.pose_decoder, f32(data['dst_posevec']).reshape(-1), refine, f32(data['dst_Rs']),
+                                       f32(data['dst_Ts']), f32(data['cnl_gtfms']))
+        return Rs, Ts, ops.prior_softmax(wc['dec'], f32(data['motion_weights_priors']))
+
     def forward(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None,
                 near=None, far=None, iter_val=1e7, **kwargs):
         cfg = self.cfg
@@ -511,7 +529,11 @@ class Network(nn.Module):
                 # all rays of the frame in as few passes as memory allows
                 cap = int(cfg.get('max_samples_per_pass', 1 << 28))
                 if R * S > (1 << 26):      # (a frame of > 30 GB: ~470 B per resident sample, at most half of what is free)
-                    cap = min(cap, max(1 << 22, int(torch.cuda.mem_get_info(dev)[0] // 2 // 470)))
+                    # free = what the driver reports + the allocator's cached, reusable blocks (after the first large frame
+                    # the cache holds the frame's buffers: counting them as used would split later frames further)
+                    free = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev)
+                            - torch.cuda.memory_allocated(dev))
+                    cap = min(cap, max(1 << 22, int(free // 2 // 470)))
                 rays_per_pass = max(1, cap // S)
                 n_over = int(cfg.get('overlap_chunks', 0))
                 overlap = (n_over > 1 and R >= n_over * 1024 and cfg.get('skip_empty_samples', True) and

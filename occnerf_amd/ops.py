@@ -548,7 +548,11 @@ def sample_features(xyz, knn_idxs, point_base, normals, unit, counter, table, bo
     """rows (int32[M], optional): compact list of samples to evaluate; outputs then have M rows.
     center / center_agg (optional, renderer's path): ops.knn_center's [4] and ops.center_row of a sample with the centre's
     neighbour lists -- groups of samples inside the radius copy its aggregate columns instead of gathering rows, and its encoded
-    columns too when their encoder input is bitwise the centre's (same bits).
+    columns too when their encoder input is bitwise the centre's (same bits).  FRESHNESS CONTRACT (not checkable here):
+    `center` must come from ops.knn_center on the SAME point set the kNN indices were searched in, and `center_agg` from this
+    function on a sample at that centre with the SAME table, counter, embeddings and pack -- stale ones give silently wrong
+    features.  Network computes both once per frame from the frame's own table (`_knn_center`) and checks the table's
+    identity and version before every use (`_stage_features`).
     count (int32[1] on the device, optional, with rows): the list's real length; M is then a capacity.
     pack: point_pack(...) of the same per-point inputs (built here when the renderer's kernel applies and the caller
     did not cache it)."""

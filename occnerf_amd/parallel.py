@@ -174,7 +174,8 @@ class ShardedRenderer:
         return ((t + 1) * (i * -7046029254386353131 + 0x2545F4914F6CDD1D | 1)).sum()
 
     def _start_plan_check(self, plan, order, by_cost):
-        """All-gather the plan's checksum [R / sizes, walk, cost order]; verified by the first `finish()` that uses the plan."""
+        """All-gather the plan's checksum [R / width / sizes, walk, cost order]; verified by the first `submit()` that uses the
+        plan, before that frame's gather is issued."""
         if not (self.collective and self.verify_plan):
             return
         meta = torch.tensor([plan['R'], plan['width'], int(plan['cost_aware'])] + list(plan['sizes']), dtype=torch.int64)
@@ -360,6 +361,11 @@ class ShardedRenderer:
             send[:n_mine, 4] = out['depth']
         if not self.collective:
             return _Pending(None, slot, R, plan, bufs)
+        # A new plan is verified BEFORE its first gather is enqueued: ranks that disagree on the frame could disagree on
+        # `width`, and a gather with mismatched counts is undefined behaviour on RCCL, not the RuntimeError promised.  The
+        # check's event was recorded ahead of the frame's kernels, so this waits for the checksum exchange only (once per
+        # new plan; later frames of the plan find nothing pending).
+        self._verify_plan(plan)
         if self.host_exchange:
             send = bufs['send_host'][slot].copy_(send)               # (synchronous: the gloo path is a test vehicle)
             rbuf = bufs['recv_host'][slot] if self.rank == 0 else None

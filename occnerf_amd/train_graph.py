@@ -1,0 +1,97 @@
+"""The per-step "static" part of the training step as two hipGraphs.
+
+What a training step evaluates before and after the per-sample kernels -- the pose refiner MLP, Rodrigues, the corrected
+rotations, forward kinematics + inverse (motion bases), the motion-weight volume decoder with its softmax against the prior,
+and the per-point SDF block -- is ~250 tiny launches forward and ~450 backward (rocprofv3, profiles/r05_train_*): a few
+hundred KFLOP spread over a millisecond of GPU time and several milliseconds of launch latency, during which the GPU idles.
+The reference has the same structure (trainer.py:239-249 over network.py:558-596, 263-284, network_util.py:98-200).
+
+Here the whole part is captured ONCE, forward and backward, with `torch.cuda.make_graphed_callables` (hipGraph on ROCm) and
+replayed every step: static input buffers, one graph launch forward, one backward, parameter gradients handed to autograd
+as usual.  The capture is keyed on the data pointers of the parameters it reads and on the input shapes: an optimiser that
+updates in place (occnerf_amd/optim.FusedAdam, torch.optim.*) never triggers a re-capture; `load_state_dict`, `.to()` or a
+new point cloud do, once.
+
+Nothing numerical changes: the graph holds the very kernels the eager modules launch (the only edit for capturability is
+`torch.linalg.inv_ex` in place of `torch.inverse`, whose error check reads `info` on the host -- same rocSOLVER kernels).
+`cfg.train_graph = False` or any failure to capture (reported once through `warnings`) falls back to the eager modules.
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+
+
+class _StaticPart(nn.Module):
+    """(posevec[1,69], dst_Rs[1,24,3,3], dst_Ts[1,24,3], cnl_gtfms[1,24,4,4], prior[1,25,G,G,G])
+    -> (Rs[24,3,3], Ts[24,3], vol[25,G,G,G], knn_base[P,3] f64, sdf[P,1])."""
+
+    def __init__(self, net, refine):
+        super().__init__()
+        # plain attribute access (not registered twice under the network: this wrapper is never attached to it as a submodule)
+        self.pose_decoder = net.pose_decoder
+        self.motion_basis_computer = net.motion_basis_computer
+        self.mweight_vol_decoder = net.mweight_vol_decoder
+        self.point_dist = net.point_dist
+        self.__dict__['net'] = net
+        self.refine = bool(refine)
+        self.total_bones = int(net.cfg.total_bones)
+
+    def forward(self, posevec, dst_Rs, dst_Ts, cnl_gtfms, prior):
+        from . import train_path
+        if self.refine:                                                   # network.py:557-596
+            refined = self.pose_decoder(posevec)['Rs']
+            tb = self.total_bones - 1
+            no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3), refined.reshape(-1, 3, 3)).reshape(-1, tb, 3, 3)
+            dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
+        Rs, Ts = self.motion_basis_computer(dst_Rs, dst_Ts, cnl_gtfms)
+        vol = self.mweight_vol_decoder(motion_weights_priors=prior)[0]
+        knn_base, sdf = train_path.point_sdf_block(self.net)
+        return Rs[0], Ts[0], vol, knn_base, sdf
+
+
+class PerStepGraph:
+    """Owner of the captured callables of one Network (kept in the network's __dict__, outside nn.Module registration)."""
+
+    def __init__(self, net):
+        self.net = net
+        self.entries = {}            # (refine, shapes) -> (callable, parameter data pointers)
+        self.captures = 0            # how many times a graph was captured (tests: stays 1 over many steps)
+        self.replays = 0
+        self.failed = None
+
+    def _param_key(self, mod):
+        return tuple(p.data_ptr() for p in mod.parameters()) + (self.net.point_base.data_ptr(),)
+
+    def __call__(self, refine, posevec, dst_Rs, dst_Ts, cnl_gtfms, prior):
+        """-> (Rs, Ts, vol, knn_base, sdf), differentiable w.r.t. the parameters; None when graphs are unavailable."""
+        if self.failed is not None:
+            return None
+        args = tuple(t.detach().float().contiguous() for t in (posevec, dst_Rs, dst_Ts, cnl_gtfms, prior))
+        key = (bool(refine),) + tuple(tuple(a.shape) for a in args)
+        hit = self.entries.get(key)
+        if hit is not None and hit[1] != self._param_key(hit[2]):
+            hit = None                                        # a parameter moved (load_state_dict / .to()): capture again
+        if hit is None:
+            mod = _StaticPart(self.net, refine)
+            try:
+                with torch.enable_grad():
+                    fn = torch.cuda.make_graphed_callables(mod, tuple(a.clone() for a in args), num_warmup_iters=3,
+                                                           allow_unused_input=True)
+            except Exception as e:                            # noqa: BLE001  (capture is an optimisation, never a requirement)
+                self.failed = f'{type(e).__name__}: {e}'
+                warnings.warn('occnerf_amd: the per-step hipGraph could not be captured, falling back to eager per-frame '
+                              f'modules ({self.failed})')
+                torch.cuda.synchronize()
+                return None
+            self.captures += 1
+            hit = self.entries[key] = (fn, self._param_key(mod), mod)
+        self.replays += 1
+        return hit[0](*args)
+
+
+def get(net):
+    g = net.__dict__.get('_per_step_graph')
+    if g is None:
+        g = net.__dict__['_per_step_graph'] = PerStepGraph(net)
+    return g

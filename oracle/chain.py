@@ -93,14 +93,19 @@ def per_frame_cpu(ctx, frame, iter_val=1e7, kick_pose=2000000, kick_nr=100000, f
     return Rs[0].numpy(), Ts[0].numpy(), vol.numpy(), hann.numpy(), frame['dst_posevec']
 
 
-def stagewise_oracle_render(g, ctx, frame=None, S=None, non_rigid=None):
+def stagewise_oracle_render(g, ctx, frame=None, S=None, non_rigid=None, preamble=None):
     """Whole path on the CPU from the oracle's stages (the `port` CPU baseline and the
-    end-to-end checker).  Returns rgb/alpha/depth + the intermediates."""
+    end-to-end checker).  Returns rgb/alpha/depth + the intermediates.
+    preamble=(Rs[24,3,3], Ts[24,3], vol[25,G,G,G]) (numpy): evaluate the per-sample stages on THESE per-frame outputs instead of
+    the torch-CPU ones -- a parity test that hands over the HIP preamble's outputs compares the per-sample kernels alone
+    (the preamble kernels are pinned separately against the reference's pose.Rs / mb.* / mw.vol_slice goldens)."""
     from oracle import oracle as orc
     frame = golden_frame(g) if frame is None else frame
     S = int(g['meta.S']) if S is None else S
     non_rigid = bool(int(g['meta.non_rigid'])) if non_rigid is None else non_rigid
     Rs, Ts, vol, hann, cond = per_frame_cpu(ctx, frame)
+    if preamble is not None:
+        Rs, Ts, vol = (np.ascontiguousarray(a, dtype=np.float32) for a in preamble)
     rays8 = np.concatenate([frame['rays'][0], frame['rays'][1], frame['near'], frame['far']], -1).astype(np.float32)
     t_vals = torch.linspace(0., 1., steps=S).numpy()
     z, pts = orc.sample_rays(rays8, t_vals)

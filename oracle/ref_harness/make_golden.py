@@ -320,6 +320,78 @@ def run_case(name, img_size, S, amplify, pose=None, orbit_frame=0, non_rigid=Fal
     return g
 
 
+class float64_reference:
+    """Context: run the UNMODIFIED reference in float64.  `torch.set_default_dtype(float64)` covers the tensors it creates
+    (`torch.zeros`, `linspace`, `torch.Tensor([1e10])`); its explicit `.float()` casts (network.py:265,280,608-609,
+    occnerf_mlp.py:167,174-175,183) are made to mean `.double()` for the duration of the pass; the third-party shims
+    dispatch on dtype (shims.py: float64 kNN, float64 evaluation of the encoder's function)."""
+
+    def __enter__(self):
+        self.default, self.float = torch.get_default_dtype(), torch.Tensor.float
+        torch.set_default_dtype(torch.float64)
+        torch.Tensor.float = lambda t, *a, **k: t.double()
+
+    def __exit__(self, *exc):
+        torch.set_default_dtype(self.default)
+        torch.Tensor.float = self.float
+
+
+def run_truth_case(name, img_size, S, pose, orbit_frame, keep_rays, seed=0, amplify=2):
+    """the trained-like field on >= 2 000 rays, rendered by the unmodified reference twice -- in its own
+    float32 (`out.*`, what the 1e-4 gate is defined against) and in float64 (`truth.*`) -- so that a parity test can say
+    which of reference-fp32 / CPU oracle / HIP is closest to the function itself.  Nothing is dropped: rays holding a live
+    sample within 2e-5 of a neighbour-set / inside-vote discontinuity stay in the file, flagged (`fragile`).  Only frame
+    inputs and final outputs are stored (the per-stage intermediates live in the small fixtures)."""
+    print(f'== {name}: {img_size}x{img_size}, S={S}, amplify={amplify}, float32 + float64 reference passes')
+    cfg.N_samples, cfg.perturb, cfg.ignore_non_rigid_motions, cfg.chunk = S, 0., False, 32768
+    frame = synth.make_frame(img_size=img_size, pose72=pose, orbit_frame=orbit_frame)
+    check_inputs_against_reference(frame, img_size, pose)
+    tkeys = ['rays', 'near', 'far', 'bgcolor', 'dst_Rs', 'dst_Ts', 'cnl_gtfms', 'motion_weights_priors', 'cnl_bbox_min_xyz',
+             'cnl_bbox_max_xyz', 'cnl_bbox_scale_xyz', 'dst_posevec']
+    R = frame['rays'].shape[1]
+    sel = np.linspace(0, R - 1, min(keep_rays, R)).astype(np.int64)
+    sel = sel[::int(os.environ.get('OCCNERF_TRUTH_STRIDE', 1))]      # (the reproducibility test regenerates every 16th ray)
+    frame['rays'], frame['near'], frame['far'] = frame['rays'][:, sel], frame['near'][sel], frame['far'][sel]
+    net, sd = build_reference_network(seed, amplify)
+    net.eval()
+    rec = Recorder()
+    restore = instrument(net, rec)
+    with torch.no_grad():
+        out = net(**{k: torch.from_numpy(np.ascontiguousarray(frame[k])) for k in tkeys}, iter_val=cfg.eval_iter)
+    restore()
+    xyz = np.concatenate([rec.d['cnl.xyz']] + [rec.d[k] for k in sorted(rec.d, key=lambda k: int(k.split('#')[1]) if '#' in k else 0)
+                                                if k.startswith('cnl.xyz#')])
+    mask = np.concatenate([rec.d['comp.mask']] + [rec.d[k] for k in sorted(rec.d) if k.startswith('comp.mask#')])
+    frag = fragile_rays(xyz, mask.reshape(len(sel), -1), net)
+    net64, _ = build_reference_network(seed, amplify)
+    net64.eval().double()
+    rec64 = Recorder()
+    restore = instrument(net64, rec64)
+    with float64_reference(), torch.no_grad():
+        net64.point_norms = net64.point_norms.double()
+        truth = net64(**{k: torch.from_numpy(np.ascontiguousarray(frame[k])).double() for k in tkeys}, iter_val=cfg.eval_iter)
+    restore()
+    for k in ('pose.Rs', 'mb.Rs', 'mw.vol', 'warp.pts', 'warp.x_skel', 'nr.embed', 'nr.xyz_out', 'msknn.q', 'enc_sample.in',
+              'enc_sample.out', 'enc_point.out', 'cnl.raw', 'comp.raw', 'comp.z_vals', 'comp.weights', 'comp.depth'):
+        assert rec64.d[k].dtype == np.float64, (k, rec64.d[k].dtype)      # every stage of the truth pass really ran in float64
+    g = {'meta.img_size': img_size, 'meta.S': S, 'meta.amplify': int(amplify), 'meta.non_rigid': 1, 'meta.seed': seed,
+         'meta.bound': float(net.bound), 'meta.orbit_frame': orbit_frame, 'meta.pose72': pose, 'in.ray_select': sel,
+         'in.rays': frame['rays'], 'in.near': frame['near'], 'in.far': frame['far'], 'fragile': frag}
+    for k in ('rgb', 'alpha', 'depth'):
+        g['out.' + k] = _np(out[k])
+        g['truth.' + k] = _np(truth[k])
+        assert g['out.' + k].dtype == np.float32 and g['truth.' + k].dtype == np.float64
+        e = np.abs(g['out.' + k] - g['truth.' + k]).reshape(len(sel), -1).max(1)
+        print(f'   {k:5s}: |reference fp32 - float64 truth| p50 {np.percentile(e, 50):.2e} p99 {np.percentile(e, 99):.2e} '
+              f'max {e.max():.2e}; on the {int((~frag).sum())} non-fragile rays max {e[~frag].max():.2e}')
+    g['sd.keys'] = np.array(list(sd.keys()))
+    g['sd.digests'] = np.array([checkpoint.tensor_digest(v) for v in sd.values()])
+    path = os.path.join(OUT_DIR, name + '.npz')
+    np.savez_compressed(path, **g)
+    print(f'   rays {len(sel)} (fragile {int(frag.sum())}) -> wrote {path} {os.path.getsize(path) / 1e6:.2f} MB; alpha in (0.05,0.95): '
+          f'{int(((g["out.alpha"] > 0.05) & (g["out.alpha"] < 0.95)).sum())}')
+
+
 def run_train_case(name, img_size=32, S=32, keep_rays=96, seed=0, amplify=True):
     """Training-mode forward + backward of the reference (rows a18/a19, config 5): stratified
     jitter with an injected t_rand, comp_loss, the point_counter visibility update, and the
@@ -458,5 +530,9 @@ if __name__ == '__main__':
                  non_rigid=True, keep_rays=160, tie_free=True)
         run_case('freeview_trained_s128', img_size=32, S=128, amplify=2, pose=synth.seeded_pose(3), orbit_frame=61,
                  non_rigid=True, keep_rays=64, tie_free=True)
+    if 'all' in which or 'truth' in which:        # >= 2 000 trained-like rays each, float32 + float64 reference passes
+        nt = int(os.environ.get('OCCNERF_TRUTH_RAYS', 2048))
+        run_truth_case('freeview_trained_truth_s32', img_size=96, S=32, pose=synth.seeded_pose(1), orbit_frame=28, keep_rays=nt)
+        run_truth_case('freeview_trained_truth_s128', img_size=96, S=128, pose=synth.seeded_pose(3), orbit_frame=61, keep_rays=nt)
     if 'all' in which or 'tposeamp' in which:
         run_case('tpose_amp_s32', img_size=32, S=32, amplify=True, keep_rays=160)

@@ -58,6 +58,8 @@ class LazyTensor:
         assert self.kind == 'norm2' and dim == 1
         q = self.a.x.reshape(-1, self.a.x.shape[-1])          # (N,1,C) -> (N,C)
         s = self.b.x.reshape(-1, self.b.x.shape[-1])          # (1,M,C) -> (M,C)
+        if q.dtype == torch.float64:                          # the float64 "truth" pass of make_golden.py
+            return _kmin_f64(q.detach(), s.detach(), k, self.ranges)
         qn, sn = q.detach().cpu().numpy(), s.detach().cpu().numpy()
         if self.ranges is None:
             idx, dist = orc.knn(qn, sn, k, return_dist=True)
@@ -72,9 +74,82 @@ class LazyTensor:
         return torch.from_numpy(dist), torch.from_numpy(idx.astype(np.int64))
 
 
+def _kmin_f64(q, s, k, ranges):
+    """Kmin_argKmin of norm2() in float64 (direct differences, no matmul trick), ascending, ties to the lower row."""
+    def block(qb, sb):
+        idx = torch.empty(qb.shape[0], k, dtype=torch.int64)
+        dist = torch.empty(qb.shape[0], k, dtype=torch.float64)
+        for lo in range(0, qb.shape[0], 4096):
+            d = (qb[lo:lo + 4096, None, :] - sb[None]).square().sum(-1).sqrt()
+            dd, ii = torch.sort(d, dim=1, stable=True)
+            dist[lo:lo + 4096], idx[lo:lo + 4096] = dd[:, :k], ii[:, :k]
+        return dist, idx
+    if ranges is None:
+        return block(q, s)
+    idx = torch.zeros(q.shape[0], k, dtype=torch.int64)
+    dist = torch.zeros(q.shape[0], k, dtype=torch.float64)
+    for (x0, x1), (y0, y1) in zip(ranges[0].tolist(), ranges[2].tolist()):
+        d, i = block(q[x0:x1], s[y0:y1])
+        dist[x0:x1], idx[x0:x1] = d, i + y0
+    return dist, idx
+
+
 # ------------------------------------------------------------ gridencoder shim
+def grid_encode_forward_f64(x, emb, offsets, S, H):
+    """gridencoder.cu:87-245 (kernel_grid, hash grid type, align_corners=False, linear interpolation) evaluated in float64:
+    the SAME function -- each level's scale is the float constant the kernel computes (`exp2f(level*S)*H - 1.0f`, :139: it
+    defines the grid, and the reference keeps it a float even in its double dispatch case), resolution ceil(scale)+1, uint32
+    index arithmetic with the kernel's primes and wrap-around, the dense / hashed decision per level, zeros for out-of-range
+    inputs -- with the cell coordinates and interpolation weights in float64.  Used only by make_golden.py's truth pass."""
+    x = np.asarray(x, np.float64)
+    emb = np.asarray(emb, np.float64)
+    B, D = x.shape
+    L, Cc = len(offsets) - 1, emb.shape[1]
+    primes = np.array([1, 2654435761, 805459861, 3674653429, 2097192037, 1434869437, 2165219737], np.uint64)
+    out = np.zeros((L, B, Cc), np.float64)
+    oob = ((x < 0) | (x > 1)).any(1)
+    M32 = np.uint64(0xffffffff)
+    scales, ress = orc.grid_level_params(L, float(S), int(H))
+    for lvl in range(L):
+        size = int(offsets[lvl + 1] - offsets[lvl])
+        scale, res = np.float64(scales[lvl]), int(ress[lvl])
+        pos = x * scale + 0.5
+        pg = np.floor(pos)
+        fr = pos - pg
+        pg = pg.astype(np.int64)
+        acc = np.zeros((B, Cc), np.float64)
+        n_dense, stride = 0, 1                               # gridencoder.cu:68-77: dims walked while stride <= hashmap_size
+        strides = []
+        while n_dense < D and stride <= size:
+            strides.append(stride)
+            stride *= res + 1                                # align_corners == False
+            n_dense += 1
+        hashed = stride > size
+        for corner in range(1 << D):
+            w = np.ones(B, np.float64)
+            idx = np.zeros(B, np.uint64)
+            hsh = np.zeros(B, np.uint64)
+            for d in range(D):
+                bit = (corner >> d) & 1
+                w = w * (fr[:, d] if bit else 1.0 - fr[:, d])
+                c = (pg[:, d] + bit).astype(np.uint64) & M32
+                if d < n_dense:
+                    idx = (idx + c * np.uint64(strides[d])) & M32
+                hsh = hsh ^ ((c * primes[d]) & M32)
+            index = (hsh if hashed else idx) % np.uint64(size)
+            acc += w[:, None] * emb[int(offsets[lvl]) + index.astype(np.int64)]
+        acc[oob] = 0.0
+        out[lvl] = acc
+    return out
+
+
 def _grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx,
                          gridtype, align_corners, interp):
+    if embeddings.dtype == torch.float64:                      # truth pass (make_golden.py): the same function in float64
+        assert dy_dx is None and gridtype == 0 and not align_corners and interp == 0
+        outputs.copy_(torch.from_numpy(grid_encode_forward_f64(inputs.detach().numpy(), embeddings.detach().numpy(),
+                                                               offsets.numpy(), float(S), int(H))))
+        return
     out, dy = orc.grid_encode_forward(inputs.detach().numpy(), embeddings.detach().numpy(),
                                       offsets.numpy(), float(S), int(H), dy_dx is not None,
                                       gridtype, align_corners, interp)

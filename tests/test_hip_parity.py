@@ -812,11 +812,21 @@ def test_network_end_to_end(case):
         print(f"   {k:5s}: max |hip - reference| {np.abs(got - g['out.' + k]).max():.3e}   max |hip - cpu oracle| {np.abs(got - o[k]).max():.3e}"
               f"   max |cpu oracle - reference| {np.abs(o[k] - g['out.' + k]).max():.3e}   (gate {tol:g})")
         assert np.abs(got - g['out.' + k]).max() <= tol, k
-        # The second checker, the CPU oracle chain, evaluates the per-frame modules with torch on THIS host's CPU: on the
-        # trained-like field (a density head with a gain of 640) that alone moves its depth by up to 1.7e-4 from the
-        # reference's (measured on the MI355X box's host; 3.6e-5 in the build container) -- the checker's noise, not the
-        # kernels': the comparison with the oracle is held to 3x the gate there.
+        # The second checker, the CPU oracle chain.  On the trained-like field (a density head with a gain of 640) two fp32
+        # evaluations of the same function differ by more than the gate on a few rays in a thousand -- MEASURED against a
+        # float64 run of the reference (profiles/r05_parity_truth.md, test_trained_truth_three_way below: the reference's own
+        # fp32 output is up to 8.8e-4 of depth from its float64 output, HIP and the oracle as far, each within 2.4e-4 of the
+        # other two).  So there the oracle comparison is held to 3x the gate with the oracle's own torch-CPU preamble, and
+        # -- separating the per-frame modules from the per-sample kernels -- to the gate itself when the oracle is fed the
+        # HIP preamble's outputs (Rs, Ts, volume; they are pinned against the reference on their own).
         assert np.abs(got - o[k]).max() <= (3 * tol if util.level(g) == 2 else tol), k
+    if util.level(g) == 2:
+        pre = tuple(t.cpu().numpy() for t in net.render_preamble(frame_to_device(g, DEV)))
+        o2 = stagewise_oracle_render(g, ctx, preamble=pre)
+        for k in ('rgb', 'alpha', 'depth'):
+            e = np.abs(out[k].cpu().numpy() - o2[k]).max()
+            print(f"   {k:5s}: max |hip - cpu oracle fed the HIP preamble's outputs| {e:.3e}")
+            assert e <= tol, k
     assert out['comp_loss'].numel() == 1
 
 
@@ -844,6 +854,62 @@ def test_rays_dropped_from_the_tie_free_fixtures(name):
         assert err.max() <= bound, (k, err)
         beyond = max(beyond, int((err > 1e-4).sum()))
     print(f'\n   {name}: {k_rays} dropped rays rendered, {beyond} beyond 1e-4 of the reference')
+    # (round 4 measured 0 on the MI355X box -- HIP broke every tie the way the reference's CPU run did; a flipped neighbour set is
+    # legitimate on other hardware, but more than a couple of them would mean something else moved)
+    assert beyond <= 2, (name, beyond)
+
+
+@pytest.mark.parametrize('name', ['freeview_trained_truth_s32', 'freeview_trained_truth_s128'])
+def test_trained_truth_three_way(name, oracle):
+    """the trained-like field on 2 048 rays per fixture, rendered by the UNMODIFIED reference twice -- in
+    its own float32 (`out.*`: what the 1e-4 gate is defined against) and in float64 (`truth.*`; make_golden.py
+    run_truth_case) -- against HIP and against the CPU oracle.  Rays holding a live sample within 2e-5 of a neighbour-set /
+    inside-vote discontinuity stay in the file, flagged; the gate is asserted on the others, the flagged ones are bounded.
+
+    What is asserted, and why it is phrased this way: on this field fp32 itself is not a 1e-4 evaluation of the function --
+    the reference's float32 output is up to 8.8e-4 (S=32) / 3.8e-4 (S=128) of depth away from its own float64 output (depth
+    is in scene units, up to 6.3), 1.5e-4 of alpha.  So (a) rgb and alpha: every non-fragile ray within 1e-4 of the reference;
+    (b) depth: within 1e-4 on >= 99.5 % of them and nowhere further from the reference's fp32 output than that output is from
+    the truth; (c) HIP and the reference's fp32 run are interchangeable estimators of the truth -- mean / p99 / max distance
+    to the truth within 10 % of the reference's, and the per-ray statement `|hip - truth| <= max(|ref - truth|, 5e-5)` holds
+    as often (to 0.5 %) as the same statement with the two exchanged; (d) the oracle shares HIP's discrete decisions bit
+    for bit, so HIP vs oracle is summation-order noise alone: within 1e-4 on >= 99.5 % of ALL rays."""
+    g = util.load_golden(name)
+    ctx = util.model_context(int(g['meta.seed']), util.level(g))
+    net, _ = build_network(int(g['meta.seed']), util.level(g), S=int(g['meta.S']), non_rigid=True)
+    assert g['in.rays'].shape[1] >= 2000
+    data = frame_to_device(g, DEV)
+    with torch.no_grad():
+        out = net(**data, iter_val=1e7)
+    o = stagewise_oracle_render(g, ctx, preamble=tuple(t.cpu().numpy() for t in net.render_preamble(data)))
+    ok = ~g['fragile']
+    assert ok.sum() >= 1800
+
+    def per_ray(a, b):
+        e = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+        return e.reshape(e.shape[0], -1).max(1)
+    print(f'\n   {name}: {ok.size} rays, {int((~ok).sum())} flagged fragile; distance to the float64 truth on the others '
+          '(max / p99 / mean) and HIP against the reference fp32 / the oracle (fed the HIP preamble)')
+    for k in ('rgb', 'alpha', 'depth'):
+        hip = out[k].cpu().numpy()
+        assert hip.shape == g['out.' + k].shape and np.isfinite(hip).all()
+        e_h, e_r, e_o = (per_ray(x, g['truth.' + k])[ok] for x in (hip, g['out.' + k], o[k]))
+        hr, ho = per_ray(hip, g['out.' + k]), per_ray(hip, o[k])
+        print(f'   {k:5s}: to truth: reference {e_r.max():.2e} / {np.percentile(e_r, 99):.2e} / {e_r.mean():.2e}   oracle '
+              f'{e_o.max():.2e} / {np.percentile(e_o, 99):.2e} / {e_o.mean():.2e}   HIP {e_h.max():.2e} / {np.percentile(e_h, 99):.2e} / '
+              f'{e_h.mean():.2e}  | HIP - reference: max {hr[ok].max():.2e}, {int((hr[ok] > 1e-4).sum())} rays > 1e-4 (fragile rays: '
+              f'max {hr[~ok].max():.2e})  | HIP - oracle: max {ho.max():.2e}, {int((ho > 1e-4).sum())} rays > 1e-4')
+        if k != 'depth':
+            assert hr[ok].max() <= 1e-4, (k, hr[ok].max())                              # (a)
+        else:
+            assert (hr[ok] <= 1e-4).mean() >= 0.995 and hr[ok].max() <= e_r.max(), (hr[ok].max(), e_r.max())      # (b)
+        assert e_h.mean() <= 1.1 * e_r.mean() + 1e-7 and np.percentile(e_h, 99) <= 1.1 * np.percentile(e_r, 99) + 1e-7 \
+            and e_h.max() <= 1.1 * e_r.max() + 1e-7, k                                 # (c)
+        f_h, f_r = (e_h <= np.maximum(e_r, 5e-5)).mean(), (e_r <= np.maximum(e_h, 5e-5)).mean()
+        assert f_h >= f_r - 0.005, (k, f_h, f_r)
+        assert (ho <= 1e-4).mean() >= 0.995 and ho.max() <= 5e-4, (k, ho.max())         # (d)
+        # the flagged rays: a flipped neighbour set moves a ray by up to ~1e-3 / 1e-2 (depth); bounded, not gated
+        assert hr[~ok].max() <= (5e-2 if k == 'depth' else 5e-3), (k, hr[~ok].max())
 
 
 def test_network_end_to_end_bf16x3(case):
@@ -1661,7 +1727,7 @@ def test_two_process_sharded_movement_at_size():
 
 
 def test_feature_kernel_row_cache_variant_is_bit_identical(ops):
-    """The opt-in per-wave row cache of the feature kernel (OCCNERF_FEATURES_ROWCACHE=1: distinct table rows of a wave trip
+    """The opt-in per-wave row cache of the feature kernel (OCCNERF_FEATURES_ROWCACHE=1 / occnerf_experiment_knob: distinct table rows of a wave trip
     staged in LDS by LDS-DMA, csrc/features.hip sample_features8r_kernel) against the shipped kernel on a 256x256 x 128 frame:
     the 68-float MLP input rows and the signed distances bit for bit (it is slower, hence opt-in: profiles/r03_features_rowcache.md)."""
     from occnerf_amd import synth
@@ -1684,13 +1750,14 @@ def test_feature_kernel_row_cache_variant_is_bit_identical(ops):
     n = int(grabbed['k']['count'])
     assert n > 96 * 64
     outs = []
-    for mode in ('0', '1'):
-        os.environ['OCCNERF_FEATURES_ROWCACHE'] = mode
+    from occnerf_amd import _lib
+    for mode in (0, 1):       # the knob is read from the environment once and switched through the C ABI afterwards
+        assert _lib.lib().occnerf_experiment_knob(b'features_rowcache', mode) >= 0
         try:
             o = real(*grabbed['a'], **grabbed['k'])
             torch.cuda.synchronize()
         finally:
-            os.environ.pop('OCCNERF_FEATURES_ROWCACHE', None)
+            _lib.lib().occnerf_experiment_knob(b'features_rowcache', 0)
         outs.append((o[0][:n].clone(), o[1][:n, 4].clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
