@@ -61,6 +61,8 @@ import torch.distributed as dist  # noqa: E402
 IMG, SPP = 512, 128
 FLOP_PER_SAMPLE_CNL = 923136          # canonical MLP, 461 568 MAC
 FLOP_PER_SAMPLE_NR = 200704           # non-rigid MLP (free-view / movement)
+PEAK_HBM_ACHIEVABLE = 6.3e12      # B/s a streaming kernel reaches on MI355X (guide); datasheet 8 TB/s
+PEAK_BF16_MFMA = 2.5e15           # dense bf16 FLOP/s (guide)
 PEAK_FP32_MFMA = 157.3e12             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 TRAIN_RAYS = 6144                     # default.yaml patch config: 6 patches x 32 x 32
 
@@ -140,6 +142,29 @@ def timed_steps(renderer, frame_h, steps, warmup, rank, world, dev, order_key, h
     return dt, [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
 
 
+# Compulsory HBM traffic of one training step of the STAGED design (one kernel per stage, intermediates in HBM), bytes per
+# sample row (M = rays x samples rows; bf16 activations = 2 B, everything else fp32).  Reads + writes of every stage's
+# operands once; gathers from cache-resident tables (hash table, per-point table, motion volume) not counted.
+TRAIN_BYTES_PER_ROW = {
+    'sampler + warp forward (xyz 12, mask 4, z 4)': 20,
+    'non-rigid MLP forward (xyz in place)': 24,
+    'multi-scale kNN (xyz 12 -> 160 B of indices)': 172,
+    'geometry / encoder inputs (xyz, idx -> mlp_in 272, raw 20, enc_in 16)': 480,
+    'aggregation weights (idx 160 -> atts 160, var 4)': 324,
+    'hash encoding forward (enc_in 16 -> 128)': 144,
+    'aggregation forward (idx 160, atts 160 -> 140)': 460,
+    'X0 assembly (agg 140, var 4, enc 128 -> 192)': 464,
+    'ten linear layers forward (inputs read, activations written once)': 8976,
+    'compositing forward + backward (raw 20, mask 4, z 4; d_raw 20, d_mask 4)': 80,
+    'linear layers backward: 10 weight-gradient passes (dZ + X) and 10 input-gradient passes (dZ + ReLU mask -> dX)': 24768,
+    'aggregation backward (grad rows 140, idx 160, atts 160, run sums 140)': 600,
+    'hash encoding backward (grad 128, enc_in 16, tile sets 16 x 8)': 272,
+    'warp backward (d_mask 4, z 4, rays)': 40,
+}
+TRAIN_PARAM_BYTES = 60.3e6 * 28 + 3 * 62e6 + 134e6      # Adam: p, m, v read + written, g read; dense embedding-gradient buffers; decoder dW
+TRAIN_FLOP_PER_ROW = 3 * FLOP_PER_SAMPLE_CNL + FLOP_PER_SAMPLE_NR      # trunks forward + dgrad + wgrad (bf16 MFMA), non-rigid forward (fp32)
+
+
 def train_leg(dev, steps, warmup):
     """BASELINE configs[4]: one optimisation step at the reference's patch configuration (6 x 32 x 32 rays, 128
     samples/ray, jitter on): forward + backward through the HIP sampler / kNN / encoder / MLP / compositor kernels
@@ -178,11 +203,30 @@ def train_leg(dev, steps, warmup):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     net.cfg.train_precision = 'auto'
-    return {'ms_per_step': dt * 1e3, 'rays_per_step': TRAIN_RAYS, 'samples_per_step': TRAIN_RAYS * SPP,
+    rows = TRAIN_RAYS * SPP
+    nbytes = rows * sum(TRAIN_BYTES_PER_ROW.values()) + TRAIN_PARAM_BYTES
+    flop = rows * TRAIN_FLOP_PER_ROW
+    t_hbm, t_mfma = nbytes / PEAK_HBM_ACHIEVABLE, flop / PEAK_BF16_MFMA
+    from occnerf_amd import train_graph
+    pg = train_graph.get(net)
+    return {'ms_per_step': dt * 1e3, 'rays_per_step': TRAIN_RAYS, 'samples_per_step': rows,
             'rays_per_s': TRAIN_RAYS / dt, 'dtype': 'bf16 MLP trunks (fp32 accumulate, fp32 master weights); '
             'fp32 sampler, encoder, aggregation, compositor', 'final_loss': float(loss.detach()),
             'what': 'forward + backward + clip_grad_norm + Adam, every per-sample stage a HIP kernel '
-                    '(occnerf_amd/train_path.py); synthetic target'}
+                    '(occnerf_amd/train_path.py); synthetic target',
+            'per_step_hipgraph': {'captures': pg.captures, 'replays': pg.replays, 'failed': pg.failed},
+            # whichever of the two rooflines takes longer bounds the step: here HBM (the layers are 256 wide: 0.26 FLOP/B)
+            'roofline': {'bound': 'hbm' if t_hbm >= t_mfma else 'mfma',
+                         'algorithmic_bytes_per_step': nbytes, 'bytes_per_row': sum(TRAIN_BYTES_PER_ROW.values()),
+                         'achieved': nbytes / dt / 1e9, 'peak': PEAK_HBM_ACHIEVABLE / 1e9, 'unit': 'GB/s',
+                         'frac': t_hbm / dt, 'hbm_floor_ms': t_hbm * 1e3,
+                         'peak_note': '6.3 TB/s = what a streaming kernel achieves on this part (MI355X_MICROARCH.md; datasheet 8 TB/s: '
+                                      'frac_of_datasheet below)', 'frac_of_datasheet': nbytes / 8.0e12 / dt,
+                         'mfma': {'flop_per_step': flop, 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',
+                                  'achieved': flop / dt / 1e12, 'frac': t_mfma / dt, 'mfma_floor_ms': t_mfma * 1e3},
+                         'bytes_per_row_breakdown': TRAIN_BYTES_PER_ROW,
+                         'note': 'compulsory traffic of the staged design (every stage one kernel, intermediates in HBM), not a '
+                                 'counter measurement; table gathers served by L2 are not counted'}}
 
 
 def config4_leg(dev, frames=3):
@@ -258,6 +302,94 @@ def movement_leg(net, dev, n_frames=12):
     return out
 
 
+def freeview_orbit_leg(net, dev, n_frames=8, first=28):
+    """A free-view orbit has a NEW camera every frame (freeview.py:133-142, camera_util.py:85-110): nothing can be named or
+    cached across frames -- rays generated on the device, the Morton walk of THEIR directions computed (csrc/rays.hip
+    occnerf_ray_order), render, device image assembly, uint8 D2H -- through the loop `run.py --type freeview` executes.
+    `n_frames` consecutive frames of the 100-step orbit starting at the headline's camera; every live sample evaluated.  The
+    per-frame cost of the order itself is shown separately (HIP events), beside the torch construction it replaced."""
+    from occnerf_amd.image import assemble_uint8_device
+    from occnerf_amd.parallel import ShardedRenderer
+    from occnerf_amd.rayorder import _order_fp32, ray_patch_order
+    from occnerf_amd.sequence import SyntheticFrames, frames_to_device, render_sequence
+    loader = SyntheticFrames('freeview', img_size=IMG, render_frames=100, device_rays=True, frame_range=(first, n_frames))
+    stage = torch.empty(IMG, IMG, 3, dtype=torch.uint8).pin_memory()
+    bg = np.array([1., 1., 1.])
+    rays = []
+
+    def on_frame(o, meta):
+        img, _ = assemble_uint8_device(meta['width'], meta['height'], meta['ray_index'], bg, o['rgb'], o['alpha'], want_alpha=False)
+        stage.copy_(img, non_blocking=True)
+        rays.append(int(meta['ray_index'].numel()))
+    net.cfg.dedup_repeated_samples = False
+    renderer = ShardedRenderer(net, dev, single=True)
+    render_sequence(renderer, loader, 'freeview', 1e7, on_frame, dev)          # warm pass
+    torch.cuda.synchronize()
+    rays.clear()
+    net._ray_orders.clear()
+    t0 = time.perf_counter()
+    render_sequence(renderer, loader, 'freeview', 1e7, on_frame, dev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the order alone, on the same frames' ray directions
+    ms_hip, ms_torch = [], []
+    with torch.no_grad():
+        for data, key, meta in frames_to_device(loader, 'freeview', dev):
+            assert key is None
+            d = data['rays'][1].contiguous()
+            for fn, acc in ((ray_patch_order, ms_hip), (_order_fp32, ms_torch)):
+                fn(d)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t1 = time.perf_counter()
+                e0.record()
+                fn(d)
+                e1.record()
+                torch.cuda.synchronize()
+                acc.append((e0.elapsed_time(e1), (time.perf_counter() - t1) * 1e3))
+    return {'workload': f'{n_frames} consecutive frames (orbit steps {first}..{first + n_frames - 1} of 100) of the free-view orbit of the '
+                        'headline pose, 512x512 x 128: a new camera every frame, ray_order_key=None, device ray generation + Morton '
+                        'order + render + device image assembly + uint8 D2H per frame; every live sample evaluated',
+            'frames': n_frames, 'value': sum(rays) / dt, 'unit': 'rays/s', 'ms_per_frame': dt / n_frames * 1e3,
+            'rays_per_frame_mean': float(np.mean(rays)),
+            'ray_order_ms_per_frame': {'hip_kernels_gpu': float(np.mean([a for a, _ in ms_hip])),
+                                       'hip_kernels_wall': float(np.mean([b for _, b in ms_hip])),
+                                       'torch_ops_gpu': float(np.mean([a for a, _ in ms_torch])),
+                                       'torch_ops_wall': float(np.mean([b for _, b in ms_torch])),
+                                       'note': 'occnerf_ray_order (3 kernels + hipcub radix sort) is what the frames above used; the '
+                                               'torch construction (~35 launches + a stable argsort) is what it replaced'}}
+
+
+def predicted_scaling_leg(net, frame_h, dev, host_out, t1_ms, frames=6):
+    """PREDICTED, SINGLE GPU -- not a scaling curve.  No multi-GPU node has been available: for N in {2, 4, 8} EVERY rank k of
+    the N-rank plan of the headline frame is emulated in this process (ShardedRenderer(emulate=(N, k)): the rank's share
+    gathered from the pinned host frame, H2D, rendered, copied to the padded send buffer, one gather on the one-rank RCCL
+    group into slot k of the N-slot receive buffer; rank 0 also un-permutes and copies the frame back to the host), pipelined
+    like the headline.  A real node's frame takes at least the slowest rank's time (+ the gather's wire time: <= 5.2 MB over
+    xGMI, ~0.05 ms).  per_rank_fixed_ms = mean over ranks of (rank time - T1 x the rank's share of the live samples): what a
+    rank spends beyond its proportional share (preamble, selects, kernel tails at 1/N of the size, launch gaps)."""
+    from occnerf_amd.parallel import ShardedRenderer
+    out = {'label': 'predicted, single GPU: every rank of the N-rank plan emulated one after the other on ONE MI355X through the '
+                    'collective renderer (one-rank RCCL group); NOT a measured scaling curve',
+           'T1_ms': t1_ms, 'worlds': {}}
+    for N in (2, 4, 8):
+        rows = []
+        for k in range(N):
+            r = ShardedRenderer(net, dev, emulate=(N, k))
+            _, step_ms = timed_steps(r, frame_h, frames, 3, 0, 1, dev, ('pred', N), host_out)
+            rays_k, live_k = r.shard_stats()
+            # median of the per-frame HIP-event times (a rank's first frames at a new shard size pay allocator misses)
+            rows.append((float(np.median(step_ms)), int(rays_k), int(live_k if live_k is not None else -1)))
+            del r
+        ms = np.array([a for a, _, _ in rows])
+        live = np.array([c for _, _, c in rows], dtype=np.float64)
+        fixed = float(np.mean(ms - t1_ms * live / live.sum())) if (live > 0).all() else None
+        out['worlds'][str(N)] = {'N': N, 'slowest_rank_ms': float(ms.max()), 'mean_rank_ms': float(ms.mean()),
+                                 'rank0_ms': float(ms[0]), 'T1_over_slowest': t1_ms / float(ms.max()),
+                                 'per_rank_fixed_ms': fixed, 'per_rank': [[round(a, 3), b, c] for a, b, c in rows]}
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -281,7 +413,7 @@ def self_launch(n):
     return child.wait()
 
 
-def rccl_world1_leg(net, frame_h, dev, steps, want, host_out):
+def rccl_world1_leg(net, frame_h, dev, steps, want, host_out, t1_ms=None):
     """The N > 1 branch of the sharded renderer on the one GPU of this box: a ONE-rank `nccl` (= RCCL) process group,
     `force_collective`: shard plan from the Morton walk + its checksum all-gather, padded send buffer, asynchronous
     dist.gather into the list-of-views receive buffer, work.wait(), un-permutation.  Pixels must equal `want` (the
@@ -298,11 +430,17 @@ def rccl_world1_leg(net, frame_h, dev, steps, want, host_out):
             out = r.finish(r.submit(frame_h, ray_order_key='bench'))['packed']
         torch.cuda.synchronize()
         R = out.shape[0]
-        return {'backend': dist.get_backend(), 'world_size_formed': dist.get_world_size(), 'collective': r.collective,
-                'gathers_issued': r.gathers_issued, 'plans_verified': r.plans_verified,
-                'bit_identical_to_headline': bool(torch.equal(out, want)),
-                'value': R * steps / dtc, 'unit': 'rays/s', 'ms_per_step': dtc / steps * 1e3,
-                'note': 'one-rank RCCL group through the N > 1 code path (dist.gather on device buffers); not the headline'}
+        res = {'backend': dist.get_backend(), 'world_size_formed': dist.get_world_size(), 'collective': r.collective,
+               'gathers_issued': r.gathers_issued, 'plans_verified': r.plans_verified,
+               'bit_identical_to_headline': bool(torch.equal(out, want)),
+               'value': R * steps / dtc, 'unit': 'rays/s', 'ms_per_step': dtc / steps * 1e3,
+               'note': 'one-rank RCCL group through the N > 1 code path (dist.gather on device buffers); not the headline'}
+        if t1_ms is not None:          # while the group exists: every rank of the 2 / 4 / 8-rank plans emulated through it
+            try:
+                res['predicted_scaling'] = predicted_scaling_leg(net, frame_h, dev, host_out, t1_ms)
+            except Exception as e:
+                res['predicted_scaling'] = {'error': f'{type(e).__name__}: {e}'[:400]}
+        return res
     finally:
         dist.destroy_process_group()
 
@@ -317,7 +455,7 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the side measurements (bf16x3, all samples, train)')
     ap.add_argument('--rccl-inline', action='store_true', help=argparse.SUPPRESS)      # (the child process of the rccl_world1 leg)
     ap.add_argument('--only', default=None, help='comma-separated side legs to run beside the headline (default: all): '
-                                                 'dedup,rccl_world1,alt,no_shortcuts,all_samples,train,movement,config4')
+                                                 'dedup,rccl_world1,alt,alt2,no_shortcuts,all_samples,train,movement,freeview_orbit,config4')
     args = ap.parse_args()
     only = None if args.only is None else set(args.only.split(','))
 
@@ -435,18 +573,23 @@ def main():
             # one-rank nccl group) under a time limit, and only its `rccl_world1` object is taken over.
             try:
                 if args.rccl_inline:
-                    side['rccl_world1'] = rccl_world1_leg(net, frame_h, dev, max(3, args.steps // 2), headline_out.to(dev), host_out)
+                    side['rccl_world1'] = rccl_world1_leg(net, frame_h, dev, max(3, args.steps // 2), headline_out.to(dev), host_out,
+                                                          t1_ms=dt / args.steps * 1e3)
                 else:
                     import subprocess
                     child = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps',
                                             str(max(3, args.steps // 2)), '--warmup', '2', '--no-cpu-baseline', '--only', 'rccl_world1',
-                                            '--rccl-inline'], capture_output=True, text=True, timeout=300,
+                                            '--rccl-inline'], capture_output=True, text=True, timeout=400,
                                            env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
                     lines = [l for l in child.stdout.splitlines() if l.startswith('{')]
                     if child.returncode != 0 or not lines:
                         raise RuntimeError(f'child rc {child.returncode}: {child.stderr[-300:]}')
                     cl = json.loads(lines[-1])
                     side['rccl_world1'] = dict(cl['rccl_world1'], headline_ms_per_step_in_child=cl['ms_per_step'])
+                    # (the 2 / 4 / 8-rank plans, every rank emulated through the child's one-rank RCCL group: its own key)
+                    ps = side['rccl_world1'].pop('predicted_scaling', None)
+                    if ps is not None:
+                        side['predicted_scaling'] = ps
             except Exception as e:
                 side['rccl_world1'] = {'error': f'{type(e).__name__}: {e}'[:400]}
         if leg('alt'):
@@ -463,6 +606,46 @@ def main():
                            'value': R * args.steps / dta, 'unit': 'rays/s', 'ms_per_step': dta / args.steps * 1e3,
                            'default': {'dedup_repeated_samples': True, 'value': R * args.steps / dtb, 'unit': 'rays/s',
                                        'ms_per_step': dtb / args.steps * 1e3}}
+            net.cfg.mlp_precision = 'fp32'
+            net.invalidate_cache()
+        if leg('alt2'):
+            # opt-in fp32-GRADE split-fp16 MLP path (cfg.mlp_precision='f16x3', csrc/split.h): same frame, same steps; never part
+            # of `value` -- the headline stays the exact fp32 kernel.  The kernel's own launches are timed with HIP events.
+            net.cfg.mlp_precision = 'f16x3'
+            net.invalidate_cache()
+            ev2, real_mlp2 = [], ops.canonical_mlp_bf16x3
+
+            def timed_mlp2(*a, **k):
+                st = torch.cuda.current_stream(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                r = real_mlp2(*a, **k)
+                e1.record(st)
+                ev2.append((e0, e1))
+                return r
+            ops.canonical_mlp_bf16x3 = timed_mlp2
+            try:
+                dta2, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
+            finally:
+                ops.canonical_mlp_bf16x3 = real_mlp2
+            torch.cuda.synchronize()
+            mlp2_ms = float(np.mean([a.elapsed_time(b) for a, b in ev2[-args.steps:]])) if ev2 else None
+            net.cfg.dedup_repeated_samples = True
+            dtb2, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
+            net.cfg.dedup_repeated_samples = False
+            live2 = float(net.last_live_count) if getattr(net, 'last_live_count', None) is not None else None
+            side['alt2'] = {'mlp_precision': 'f16x3 (two fp16 pieces per operand kept in the normal range: 22 significand bits, 3 MFMA '
+                                             'products on v_mfma_f32_32x32x16_f16, fp32 accumulate): meets the fp32 kernel\'s own tolerances '
+                                             'and the 1e-4 pixel gate on all three checkpoints (tests/test_hip_parity.py *_f16x3); domain: '
+                                             'hidden activations below 4 094',
+                            'value': R * args.steps / dta2, 'unit': 'rays/s', 'ms_per_step': dta2 / args.steps * 1e3,
+                            'canonical_mlp_launch_ms': mlp2_ms,
+                            'canonical_mlp_algorithmic_tflops': None if not (mlp2_ms and live2) else
+                            FLOP_PER_SAMPLE_CNL * live2 / (mlp2_ms * 1e-3) / 1e12,
+                            'note': 'algorithmic TFLOP/s = the network\'s 923 136 FLOP/sample over the launch time (the kernel executes 3x '
+                                    'that on the fp16 pipe, peak 2 500 dense); not comparable with the fp32 roofline fraction',
+                            'default': {'dedup_repeated_samples': True, 'value': R * args.steps / dtb2, 'unit': 'rays/s',
+                                        'ms_per_step': dtb2 / args.steps * 1e3}}
             net.cfg.mlp_precision = 'fp32'
             net.invalidate_cache()
         if leg('no_shortcuts'):
@@ -491,6 +674,8 @@ def main():
             side['train'] = train_leg(dev, max(5, args.steps // 2), 3)
         if leg('movement'):
             side['movement'] = movement_leg(net, dev)
+        if leg('freeview_orbit'):
+            side['freeview_orbit'] = freeview_orbit_leg(net, dev)
         if leg('config4'):
             del renderer
             torch.cuda.empty_cache()
@@ -542,8 +727,10 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'occ::m16::canonical_mlp_lds_kernel (fp32 MFMA 16x16x4, LDS-staged weights)',
                          'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA, 'traffic': traffic,
-                         'traffic_note': f'HBM bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/{traffic_src}; '
-                                         'algorithmic 288 B/sample',
+                         'traffic_note': f'NOT measured in this run: read from the committed file profiles/{traffic_src} (separate '
+                                         'rocprofv3 --pmc passes over this very launch size, tools/pmc_hbm.sh: HBM bytes per '
+                                         'launch = FETCH_SIZE x2 + WRITE_SIZE with the guide\'s gfx950 corrections); null when no '
+                                         'committed pass matches the launch size; algorithmic 288 B/sample',
                          'launch_ms': avg_ms, 'launches_timed': len(ms),
                          'flop_per_launch': FLOP_PER_SAMPLE_CNL * float(np.mean(nsmp)),
                          # the second MFMA kernel of the frame (rank 0's launches): algorithmic 200 704 FLOP per live sample

@@ -30,8 +30,8 @@ extern "C" {
 
 /* Bumped whenever an existing export's signature or a table layout changes (2: composite/msknn_clustered/
  * sample_features grew arguments in round 2, the Adam table row carries per-tensor bias corrections; 3: msknn_clustered
- * takes the cluster groups). */
-#define OCCNERF_ABI_VERSION 3
+ * takes the cluster groups; 4: occnerf_agg_backward takes a scratch buffer). */
+#define OCCNERF_ABI_VERSION 4
 
 int occnerf_abi_version(void);
 const char *occnerf_last_error(void);
@@ -39,7 +39,8 @@ const char *occnerf_last_error(void);
 /* Experiment knobs: kernel variants that were measured and not shipped stay selectable for A/B runs.  Each knob
  * is read from its environment variable once, at first use, and clamped to its valid range; this call reads (value < 0) or
  * sets it afterwards.  Names: "cohab_lds" (OCCNERF_COHAB_LDS, bytes of padding LDS, 0..131072), "features_small"
- * (OCCNERF_FEATURES_SMALL, 0/1), "features_rowcache" (OCCNERF_FEATURES_ROWCACHE, 0/1).  Returns the previous value, -1 for an
+ * (OCCNERF_FEATURES_SMALL, 0/1), "features_rowcache" (OCCNERF_FEATURES_ROWCACHE, 0/1), "agg_slices" (OCCNERF_AGG_SLICES,
+ * 0 = automatic, else the sample slices of occnerf_agg_backward).  Returns the previous value, -1 for an
  * unknown name.  No counterpart in the reference. */
 int occnerf_experiment_knob(const char *name, int value);
 
@@ -82,6 +83,13 @@ int occnerf_grid_encode_forward_h(const float *inputs, const float *embeddings, 
                                   const int32_t *h_offsets, float *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                   float S, uint32_t H, float *dy_dx, uint32_t gridtype, int align_corners,
                                   uint32_t interp, void *stream);
+
+/* Host-side helper of the module's backward (grid.py:69-90 permutes autograd's [B, L*C] gradient to [L,B,C] before the
+ * operator call): the same transposition with the rows of RUNS of consecutive samples whose inputs are bitwise identical
+ * summed into the run's first sample, zeros in the others (the tiled backward skips zero rows).  Same gradient (another
+ * summation order); only when no input gradient is wanted.  No counterpart in the reference. */
+int occnerf_grid_grad_runs(const float *grad_rows, const float *inputs, int64_t B, uint32_t D, uint32_t L, uint32_t C,
+                           float *grad, void *stream);
 
 /* occnerf_grid_encode_backward with the level offsets also given as a HOST array h_offsets[L+1].  The
  * reference's signature above cannot know the level sizes without reading device memory, so it always runs
@@ -141,6 +149,17 @@ int occnerf_sample_warp_culled(const float *rays, int64_t n, int32_t S, const fl
                                const float *Rs, const float *Ts, const float *vol, int32_t nb, int32_t G,
                                const int32_t *boxes, const float *h_bbox_min, const float *h_bbox_scale,
                                float *z_vals, float *x_skel, float *mask, void *stream);
+
+/* Render order of a frame's rays: the permutation that walks them along a 2-D Morton curve of their directions (projected on
+ * the plane normal to the mean direction), so that 64 consecutive rays are a compact ~8x8 pixel patch (kNN tiles, hash-grid
+ * gathers) and 256 a ~16x16 one (the block a rank is dealt).  No counterpart in the reference, whose ray order is the
+ * dataset's (freeview.py:190-208 row-major pixels); rays are independent, results are returned in the caller's order.
+ * dirs: R directions `stride` floats apart (3: a [R,3] array; 8: columns 3..5 of rays8); order[R] int64 out; temp:
+ * occnerf_ray_order_temp_bytes(R) bytes.  Deterministic (fixed-order reductions + a stable radix sort): every rank of a
+ * sharded render computes the same walk from the same frame. */
+int64_t occnerf_ray_order_temp_bytes(int64_t R);
+int occnerf_ray_order(const float *dirs, int64_t R, int64_t stride, int64_t *order, void *temp, int64_t temp_bytes,
+                      void *stream);
 
 /* Per-frame ray generation (one thread per pixel): camera_util.py:133-160 get_rays_from_KRT +
  * :163-212 rays_intersect_3d_bbox, as the reference's datasets call them (tpose.py:155-172,
@@ -332,13 +351,16 @@ int occnerf_sample_features_centered(const float *xyz, int64_t N, const int32_t 
  * gather of :176-178): agg[n,:] = sum_j atts[n,j] * feats[knn[n,j],:] for feats[P,F] (F <= 64), knn[N,K],
  * atts[N,K] (detached in the reference).  Backward: partial[W,P,F] with W = occnerf_agg_backward_slices(N);
  * every element is written, grad_feats = partial.sum(0).  Workgroups own (sample slice, point tile) pairs
- * and accumulate in LDS -- no global atomics.  Replaces torch's feats[knn] materialisation and its index_put
- * backward. */
+ * and accumulate in LDS -- no global atomics; a first pass sums the gradient rows of runs of consecutive samples with
+ * identical neighbour lists (K <= 64; atts must be a function of the ids, as simple_agg's are) into `scratch`
+ * (occnerf_agg_backward_scratch_bytes(N, F) bytes) so that a run is scattered once.  Replaces torch's feats[knn]
+ * materialisation and its index_put backward. */
 int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *knn, const float *atts, int64_t N, int32_t K,
                         float *agg, void *stream);
 int32_t occnerf_agg_backward_slices(int64_t N);
+int64_t occnerf_agg_backward_scratch_bytes(int64_t N, int32_t F);
 int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t *knn, const float *atts, int64_t N,
-                         int32_t K, int32_t P, float *partial, void *stream);
+                         int32_t K, int32_t P, float *partial, void *scratch, int64_t scratch_bytes, void *stream);
 
 /* Live samples of a frame (mask = per-sample motion-weight sum, network.py:330: alpha is multiplied by it).
  * rows[0 .. *count) = ascending indices of the samples with mask != 0, both in device memory; temp = device
@@ -426,6 +448,23 @@ int occnerf_canonical_mlp_bf16x3_rows(const float *mlp_in, const int32_t *in_row
                                       const int32_t *n_dev, const float *packed, const void *packed_bf16,
                                       float *raw, int32_t variant, void *stream);
 
+/* Opt-in fp32-GRADE split (cfg.mlp_precision = 'f16x3'): occnerf_mlp.py:183-199 / mlp_offset.py:45-62 on
+ * v_mfma_f32_32x32x16_f16 with every operand cut into two fp16 pieces kept in the normal range -- 22 significand bits per
+ * operand (fp32: 24), three products, fp32 accumulation (csrc/split.h F16x3: activations travel scaled by 16, the weights'
+ * low piece scaled by 2^11 against xh 2^-11; subnormal inputs are preserved by the instruction, measured with
+ * tools/mfma_f16_probe.hip).  Domain: hidden activations below 65504 / 16 = 4 094 (larger ones saturate there).
+ * packed_f16: the same byte count and layout as the bf16 stream (occnerf_canonical_mlp_packed_bf16_bytes /
+ * occnerf_nonrigid_packed_bf16_bytes, zero-initialised), written by the _pack_f16 call; packed: the fp32 blob (biases, head
+ * rows).  in_rows / rows and n_dev nullable (every row, N_max entries); with a list the count is read from device memory.
+ * The non-rigid call may run in place (xyz_out == xyz_in); with rows the offsets go to the listed samples. */
+int occnerf_canonical_mlp_pack_f16(const float *const *h_W, void *packed_f16, void *stream);
+int occnerf_canonical_mlp_f16x3(const float *mlp_in, const int32_t *in_rows, int64_t N_max, const int32_t *n_dev,
+                                const float *packed, const void *packed_f16, float *raw, void *stream);
+int occnerf_nonrigid_pack_f16(const float *const *h_W, void *packed_f16, void *stream);
+int occnerf_nonrigid_f16x3(const float *xyz_in, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
+                           const float *cond, const float *h_hann, const float *W0, const float *b0, float *packed,
+                           const void *packed_f16, float *xyz_out, void *stream);
+
 /* Alpha compositing, network.py:320-348.  raw[n,S,5], mask[n*S], z_vals[n,S],
  * rays[n,8] (direction at floats 3..5), h_bgcolor[3] host, 0..255.
  * Outputs rgb[n,3], acc[n], depth[n]; weights[n,S] and term[n] (argmax alpha) optional.
@@ -492,6 +531,16 @@ int occnerf_warp_backward(const float *rays, int64_t n, int32_t S, const float *
  * (softmax) and var[N] (unbiased variance of the normalised counts). */
 int occnerf_agg_weights(const float *counter, const int32_t *knn, int64_t N, int32_t K, float *atts, float *var,
                         void *stream);
+
+/* Training step: gradients of the pose refiner's five Linear layers through the chain occnerf_pose_motion_bases evaluates
+ * (mlp_delta_body_pose.py:35-41, network_util.py:98-124 Rodrigues, network.py:535-539, network_util.py:166-200 forward
+ * kinematics + inverse), given the cotangents dRs[24,3,3], dTs[24,3] of its outputs -- what torch autograd derives in ~460
+ * tiny launches per step (trainer.py:239-249).  One workgroup; the forward is recomputed inside.  h_dW[l] / h_db[l]: device
+ * buffers shaped like layer l's weight / bias, overwritten.  Only meaningful with refinement on. */
+int occnerf_pose_motion_bases_backward(const float *const *h_W, const float *const *h_b, const float *posevec,
+                                       const float *dst_Rs, const float *dst_Ts, const float *cnl_gtfms,
+                                       const float *dRs, const float *dTs, float *const *h_dW, float *const *h_db,
+                                       void *stream);
 
 /* Per-frame preamble.
  * occnerf_pose_motion_bases: pose refiner + motion bases in one launch.  h_W/h_b: HOST arrays of the 5 device weight /

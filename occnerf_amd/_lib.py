@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCCNERF_HIP_LIB=<path>: load another build of the same library (A/B timing of kernel variants); never a different backend
 LIB_PATH = os.environ.get('OCCNERF_HIP_LIB') or os.path.join(_HERE, 'liboccnerf_hip.so')
 
-ABI_VERSION = 3          # include/occnerf_hip.h OCCNERF_ABI_VERSION this binding mirrors
+ABI_VERSION = 4          # include/occnerf_hip.h OCCNERF_ABI_VERSION this binding mirrors
 
 _vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
@@ -23,6 +23,7 @@ SIGNATURES = {
                                                _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grid_encode_backward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
                                                 _u32, _vp, _vp, _u32, C.c_int, _u32, _vp]),
+    'occnerf_grid_grad_runs': (C.c_int, [_vp, _vp, _i64, _u32, _u32, _u32, _vp, _vp]),
     'occnerf_grid_encode_forward_h': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32,
                                                  _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grid_encode_backward_h': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
@@ -54,10 +55,13 @@ SIGNATURES = {
     'occnerf_knn_small': (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'occnerf_unit_normals': (C.c_int, [_vp, _i32, _vp, _vp]),
     'occnerf_point_sdf': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    'occnerf_ray_order_temp_bytes': (_i64, [_i64]),
+    'occnerf_ray_order': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     'occnerf_gen_rays': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_agg_forward': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     'occnerf_agg_backward_slices': (_i32, [_i64]),
-    'occnerf_agg_backward': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    'occnerf_agg_backward_scratch_bytes': (_i64, [_i64, _i32]),
+    'occnerf_agg_backward': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     'occnerf_live_rows_temp_bytes': (_i64, [_i64]),
     'occnerf_live_rows': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     'occnerf_scatter_raw': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
@@ -86,6 +90,10 @@ SIGNATURES = {
     'occnerf_canonical_mlp_packed_bf16_bytes': (_i64, []),
     'occnerf_canonical_mlp_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_canonical_mlp_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    'occnerf_canonical_mlp_pack_f16': (C.c_int, [_vp, _vp, _vp]),
+    'occnerf_canonical_mlp_f16x3': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_nonrigid_pack_f16': (C.c_int, [_vp, _vp, _vp]),
+    'occnerf_nonrigid_f16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp_bf16x3_rows': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
     'occnerf_composite': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_linear_pack': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
@@ -99,6 +107,7 @@ SIGNATURES = {
     'occnerf_warp_backward': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_agg_weights': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'occnerf_pose_motion_bases': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_pose_motion_bases_backward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_prior_softmax': (C.c_int, [_vp, _vp, _i32, _i64, _vp, _vp]),
     'occnerf_pack_rays': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'occnerf_assemble_image': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -94,8 +94,9 @@ _DEFAULTS = {
     # the device memory that is free when the frame starts (Network.forward: min(this, free / 2 / 470 B)), so a smaller GPU
     # or ranks sharing one device split a large frame instead of running out of memory.
     'max_samples_per_pass': 1 << 28,
-    # 'fp32': exact fp32 MFMA (default, the parity/benchmark path); 'bf16x3': split-bf16 MFMA,
-    # ~3x faster MLP, raw logits within ~1e-5 of fp32
+    # 'fp32': exact fp32 MFMA (default, the parity/benchmark path); 'f16x3': split-fp16 MFMA with scaled pieces, 22
+    # significand bits per operand -- fp32-grade (csrc/split.h; domain: hidden activations below 4 094); 'bf16x3':
+    # split-bf16 MFMA, 16 bits per operand (meets the pixel gate on the random-init checkpoint only)
     'mlp_precision': 'fp32',
     'skip_empty_samples': True,      # drop samples whose motion-weight sum is exactly 0 (identical pixels)
     'device_rays': True,             # run.py: generate the frame's ray batch on the GPU (occnerf_amd/rays.py)

@@ -36,44 +36,115 @@ __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restric
 
 // Backward.  Global fp32 atomics are memory-side operations on this part (~20 G/s even on a 1 MB table:
 // 54 ms for one training batch), so the scatter is organised by OWNERSHIP instead: workgroup (w, tile) owns
-// the gradient rows of kTilePoints consecutive points for the w-th slice of the samples, keeps them in LDS,
-// scans its samples (one wave per sample: the 40 ids in 40 lanes, ballot of the ones in the tile, then one
-// LDS atomic instruction per hit with lane c = column c) and finally stores the tile to partial[w] with plain
-// writes; the caller sums the W partial tables.  No global atomics.  The LDS accumulators are fp64: ds_add_f64
-// runs at 16 cycles per wave-instruction on gfx950, ds_add_f32 at 190 (tools/lds_atomic_rate.hip) -- and the
-// sums come out more accurate for it.
+// the gradient rows of `tile_points` consecutive points for the w-th slice of the samples, keeps them in LDS as fp64
+// (ds_add_f64 runs at 16 cycles per wave-instruction on gfx950, ds_add_f32 at 190: tools/lds_atomic_rate.hip -- and the
+// sums come out more accurate for it), and stores the tile to partial[w] with plain writes; the caller sums the W
+// partial tables.  No global atomics.
+//
+// Round 5 -- two passes.  (Measured: with every (tile, slice) job scanning its slice's ids + weights + gradient rows,
+// 460 B per sample, the kernel lasted as long as 14 x that scan -- 2.8 ms -- whatever the atomics did.)
+//   1. agg_runs_kernel, once over the samples: wherever a sample's motion-weight sum is far below the warp's 1e-4 clamp
+//      its canonical position collapses onto one point (network.py:388; two thirds of a frame's live samples), so
+//      consecutive samples of a ray carry the SAME 40 neighbour ids in the same order -- hence the same softmax weights,
+//      a function of the ids alone (occnerf_mlp.py:110-125).  A wave walks 64 contiguous samples, sums the gradient rows
+//      of each run of identical id lists (fp64 in registers) into the row of the run's FIRST sample, and writes per sample
+//      a bit mask of the point tiles its ids touch -- zero for every sample but a run's first, and for runs whose summed
+//      row is exactly zero (dead samples: alpha is multiplied by a zero mask).
+//   2. agg_backward_tiled_kernel: a (tile, slice) job reads 4 bytes per sample -- the masks, coalesced -- and fetches
+//      ids / weights / summed row only for the samples whose mask has its bit: a run's 40 LDS atomics are issued once.
 constexpr int kAggTileValues = 18432;            // doubles: 144 KiB of LDS
+constexpr int kAggRun = 64;                      // samples a wave walks for runs (half a ray at 128 samples / ray)
 
-__global__ __launch_bounds__(1024) void agg_backward_tiled_kernel(const float *__restrict__ grad_agg, int F,
+__global__ __launch_bounds__(256) void agg_runs_kernel(const float *__restrict__ grad_agg, int F,
+                                                       const int32_t *__restrict__ knn, int64_t N, int K, int tile_points,
+                                                       int tiles, float *__restrict__ gsum /*[N][F]*/,
+                                                       uint32_t *__restrict__ mask /*[N]*/) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kAggRun;
+    if (c0 >= N) return;
+    const int64_t c1 = c0 + kAggRun < N ? c0 + kAggRun : N;
+    constexpr int U = 8;
+    int cur_id = -2;                 // the open run's id list (lane j: neighbour j) ...
+    double acc = 0.0;                // ... the sum of its gradient rows (lane c: column c) ...
+    int head = -1;                   // ... and its first sample (offset in the chunk)
+    uint32_t my_mask = 0;            // lane i: mask of sample c0 + i
+    auto flush = [&]() {
+        const float v = (float)acc;
+        if (__builtin_amdgcn_ballot_w64(lane < F && v != 0.0f) == 0ull) return;          // the run adds nothing
+        if (lane < F) gsum[(c0 + head) * F + lane] = v;
+        const int t = lane < K ? cur_id / tile_points : -1;
+        uint32_t m = 0;
+        for (int tt = 0; tt < tiles; tt++)
+            if (__builtin_amdgcn_ballot_w64(t == tt) != 0ull) m |= 1u << tt;
+        if (lane == head) my_mask = m;
+    };
+    for (int64_t nb = c0; nb < c1; nb += U) {
+        float g[U];
+        int my_id[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t n = nb + u < c1 ? nb + u : c1 - 1;
+            g[u] = lane < F ? grad_agg[n * F + lane] : 0.0f;
+            my_id[u] = lane < K ? knn[n * K + lane] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (nb + u >= c1) break;
+            if (head < 0 || __builtin_amdgcn_ballot_w64(my_id[u] != cur_id) != 0ull) {
+                if (head >= 0) flush();
+                cur_id = my_id[u];
+                acc = 0.0;
+                head = (int)(nb + u - c0);
+            }
+            acc += (double)g[u];
+        }
+    }
+    if (head >= 0) flush();
+    if (c0 + lane < c1) mask[c0 + lane] = my_mask;
+}
+
+__global__ __launch_bounds__(1024) void agg_backward_tiled_kernel(const float *__restrict__ gsum, int F,
                                                                   const int32_t *__restrict__ knn,
-                                                                  const float *__restrict__ atts, int64_t N, int K,
+                                                                  const float *__restrict__ atts,
+                                                                  const uint32_t *__restrict__ mask, int64_t N, int K,
                                                                   int P, int tile_points, int64_t samples_per_slice,
                                                                   float *__restrict__ partial /*[W][P][F]*/) {
     __shared__ double s_g[kAggTileValues];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int tile0 = blockIdx.y * tile_points;
+    const int tile = blockIdx.y, tile0 = tile * tile_points;
     const int tile_n = P - tile0 < tile_points ? P - tile0 : tile_points;
     for (int i = threadIdx.x; i < tile_n * F; i += blockDim.x) s_g[i] = 0.0;
     __syncthreads();
     const int64_t n0 = (int64_t)blockIdx.x * samples_per_slice;
     const int64_t n1 = n0 + samples_per_slice < N ? n0 + samples_per_slice : N;
-    // The loop is latency-bound (three dependent-free loads per sample, then a handful of LDS atomics): eight samples
-    // per trip keep 24 loads in flight per wave.  K <= 64 (one id per lane) on this path; larger K falls back below.
-    constexpr int U = 8;
-    if (K <= 64) {
-        for (int64_t nb = n0 + (int64_t)wave * U; nb < n1; nb += (int64_t)nwaves * U) {
+    constexpr int U = 4;             // listed samples fetched together (12 independent loads in flight per wave)
+    for (int64_t c0 = n0 + (int64_t)wave * 64; c0 < n1; c0 += (int64_t)nwaves * 64) {
+        const uint32_t m = c0 + lane < n1 ? mask[c0 + lane] : 0u;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64((m >> tile) & 1u);
+        while (todo) {
+            int64_t n[U];
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                n[u] = -1;
+                if (todo) {
+                    n[u] = c0 + __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    cnt = u + 1;
+                }
+            }
             float g[U], my_w[U];
             int my_id[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int64_t n = nb + u < n1 ? nb + u : n1 - 1;
-                g[u] = lane < F ? grad_agg[n * F + lane] : 0.0f;
-                my_id[u] = lane < K ? knn[n * K + lane] : -1;
-                my_w[u] = lane < K ? atts[n * K + lane] : 0.0f;
+                const int64_t nn = n[u] >= 0 ? n[u] : n[0];
+                g[u] = lane < F ? gsum[nn * F + lane] : 0.0f;
+                my_id[u] = lane < K ? knn[nn * K + lane] : -1;
+                my_w[u] = lane < K ? atts[nn * K + lane] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (nb + u >= n1) break;
+                if (u >= cnt) break;
                 const unsigned rel = (unsigned)(my_id[u] - tile0);
                 unsigned long long hits = __builtin_amdgcn_ballot_w64(lane < K && rel < (unsigned)tile_n);
                 while (hits) {
@@ -81,25 +152,7 @@ __global__ __launch_bounds__(1024) void agg_backward_tiled_kernel(const float *_
                     hits &= hits - 1;
                     const int p = __builtin_amdgcn_readlane(my_id[u], j) - tile0;
                     const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w[u]), j));
-                    if (lane < F) atomicAdd(&s_g[p * F + lane], (double)__fmul_rn(wj, g[u]));
-                }
-            }
-        }
-    } else {
-        for (int64_t n = n0 + wave; n < n1; n += nwaves) {
-            const float g = lane < F ? grad_agg[n * F + lane] : 0.0f;
-            for (int j0 = 0; j0 < K; j0 += 64) {
-                const int jj = j0 + lane;
-                const int my_id = jj < K ? knn[n * K + jj] : -1;
-                const float my_w = jj < K ? atts[n * K + jj] : 0.0f;
-                const unsigned rel = (unsigned)(my_id - tile0);
-                unsigned long long hits = __builtin_amdgcn_ballot_w64(jj < K && rel < (unsigned)tile_n);
-                while (hits) {
-                    const int j = __builtin_ctzll(hits);
-                    hits &= hits - 1;
-                    const int p = __builtin_amdgcn_readlane(my_id, j) - tile0;
-                    const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
-                    if (lane < F) atomicAdd(&s_g[p * F + lane], (double)__fmul_rn(wj, g));
+                    if (lane < F) atomicAdd(&s_g[p * F + lane], (double)wj * (double)g[u]);
                 }
             }
         }
@@ -108,6 +161,8 @@ __global__ __launch_bounds__(1024) void agg_backward_tiled_kernel(const float *_
     float *dst = partial + ((size_t)blockIdx.x * P + tile0) * F;
     for (int i = threadIdx.x; i < tile_n * F; i += blockDim.x) dst[i] = (float)s_g[i];
 }
+
+static int agg_tile_points(int F) { return kAggTileValues / F < 1024 ? kAggTileValues / F : 1024; }
 
 }  // namespace occ
 
@@ -125,25 +180,43 @@ OCC_API int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *kn
 }
 
 OCC_API int32_t occnerf_agg_backward_slices(int64_t N) {
-    // Sample slices W (x 14 point tiles = workgroups).  Per-job times measured with wall_clock64 at 786 K samples and 24
-    // slices: ~1.0 ms for most (point tile, slice) jobs but 3.8 ms for every slice of ONE tile (the points most samples are
-    // near), which set the kernel's 4.7 ms.  48 slices halve every job, the hot ones then spread over two rounds of the 256
-    // CUs: 2.9 ms.  (18 slices = a single round was slower, 5.4 ms.)
-    int64_t w = (N + 16383) / 16384;
-    return (int32_t)(w < 1 ? 1 : (w > 48 ? 48 : w));
+    // Sample slices W (x 14 point tiles = workgroups).  Measured in round 5 (tools/debug_agg.py): after the run pre-pass a job's
+    // time is its LDS atomics -- ~69 cycles each when they pile onto a few rows (a slice's samples share their neighbours), and
+    // the tiles differ 30x in hits (1.07 M pairs in the hottest, 33 K in the lightest) -- so the slices are made small enough
+    // for the hardware's workgroup scheduler to balance the hot tile's jobs against everyone else's: up to 256 slices of
+    // >= 3 072 samples (786 432 samples: 48 slices 2.15 ms, 96 1.87, 128 1.65, 192 1.44, 256 1.23, partial-table sum included).
+    // The experiment knob "agg_slices" (OCCNERF_AGG_SLICES) overrides for A/B runs.
+    const int forced = occ::knob(occ::kKnobAggSlices);
+    if (forced >= 1) return forced;
+    int64_t w = (N + 3071) / 3072;
+    return (int32_t)(w < 1 ? 1 : (w > 256 ? 256 : w));
+}
+
+/* bytes of scratch occnerf_agg_backward needs: the run sums [N][F] fp32 + the tile masks [N] */
+OCC_API int64_t occnerf_agg_backward_scratch_bytes(int64_t N, int32_t F) {
+    if (N <= 0 || F < 1) return 0;
+    return ((N * F * 4 + 255) & ~(int64_t)255) + N * 4;
 }
 
 OCC_API int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t *knn, const float *atts, int64_t N,
-                                 int32_t K, int32_t P, float *partial, void *stream) {
+                                 int32_t K, int32_t P, float *partial, void *scratch, int64_t scratch_bytes, void *stream) {
     using namespace occ;
     if (N <= 0) return 0;
-    OCC_REQUIRE(grad_agg && knn && atts && partial, "agg_backward: null argument");
-    OCC_REQUIRE(F >= 1 && F <= 64 && K >= 1 && P >= 1, "agg_backward: F=%d (1..64), K=%d, P=%d", F, K, P);
+    OCC_REQUIRE(grad_agg && knn && atts && partial && scratch, "agg_backward: null argument");
+    OCC_REQUIRE(F >= 1 && F <= 64 && K >= 1 && K <= 64 && P >= 1, "agg_backward: F=%d (1..64), K=%d (1..64), P=%d", F, K, P);
+    OCC_REQUIRE(scratch_bytes >= occnerf_agg_backward_scratch_bytes(N, F), "agg_backward: scratch too small");
     const int W = occnerf_agg_backward_slices(N);
-    const int tile_points = kAggTileValues / F < 1024 ? kAggTileValues / F : 1024;
+    const int tile_points = agg_tile_points(F);
     const int tiles = (P + tile_points - 1) / tile_points;
-    const int64_t per_slice = (N + W - 1) / W;
-    hipLaunchKernelGGL(agg_backward_tiled_kernel, dim3(W, tiles), dim3(1024), 0, as_stream(stream), grad_agg, F, knn,
-                       atts, N, K, P, tile_points, per_slice, partial);
+    OCC_REQUIRE(tiles <= 32, "agg_backward: %d point tiles (P=%d): at most 32", tiles, P);
+    float *gsum = reinterpret_cast<float *>(scratch);
+    uint32_t *mask = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(scratch) + ((N * F * 4 + 255) & ~(int64_t)255));
+    const int64_t chunks = (N + kAggRun - 1) / kAggRun;
+    OCC_REQUIRE((chunks + 3) / 4 < (1ll << 31), "agg_backward: N too large");
+    hipLaunchKernelGGL(agg_runs_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, as_stream(stream), grad_agg, F, knn, N, K,
+                       tile_points, tiles, gsum, mask);
+    const int64_t per_slice = (((N + W - 1) / W) + kAggRun - 1) / kAggRun * kAggRun;      // whole chunks: runs never straddle a slice
+    hipLaunchKernelGGL(agg_backward_tiled_kernel, dim3(W, tiles), dim3(1024), 0, as_stream(stream), gsum, F, knn, atts, mask,
+                       N, K, P, tile_points, per_slice, partial);
     return check_launch("agg_backward");
 }

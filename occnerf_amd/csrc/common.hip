@@ -26,7 +26,8 @@ struct KnobSpec {
 // at most what a gfx950 workgroup can still ask for beside those kernels' static LDS.
 static const KnobSpec kKnobSpecs[kKnobCount] = {{"cohab_lds", "OCCNERF_COHAB_LDS", 0, 128 * 1024},
                                                 {"features_small", "OCCNERF_FEATURES_SMALL", 0, 1},
-                                                {"features_rowcache", "OCCNERF_FEATURES_ROWCACHE", 0, 1}};
+                                                {"features_rowcache", "OCCNERF_FEATURES_ROWCACHE", 0, 1},
+                                                {"agg_slices", "OCCNERF_AGG_SLICES", 0, 1024}};
 static std::atomic<int> g_knob[kKnobCount];
 static std::atomic<bool> g_knob_read[kKnobCount];
 

@@ -26,6 +26,7 @@
 // MFMA count per wave: 288 + 3*1024 + 256 + 544 + 3*1024 = 7232 (ideal 7212): 99.7 % of
 // the issued matrix work is algorithmic.  Roofline: fp32 MFMA, 157.3 TFLOP/s.
 #include "common.h"
+#include "split.h"
 
 namespace occ {
 
@@ -282,8 +283,6 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_kernel(const float *__re
 // next layer's B operands after bias/ReLU and the hi/lo split (done in registers, 3 VALU per
 // value).  A k-step is now 16 wide: lane half h supplies 8 consecutive registers of a block.
 // =======================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int kS_L0Geo = 5;                 // ceil(34 / 8) k-steps of 16 (8 per half-wave)
 constexpr int kS_Hidden = kWidth / 16;      // 16
 constexpr int kS_L0Rgb = 4 + 5;             // 64 geometry features + 34 x-slots
@@ -300,8 +299,9 @@ struct BlobH {
     static constexpr int64_t kTotal = kRgbH + 3 * kHiddenStride;            // in bf16x8 units
 };
 
-__global__ void pack_layer_bf16_kernel(const float *__restrict__ W, int kind, int in_dim, int out_dim,
-                                       int steps, int ob_count, __bf16 *__restrict__ Wp) {
+template <typename P>
+__global__ void pack_layer_split_kernel(const float *__restrict__ W, int kind, int in_dim, int out_dim,
+                                        int steps, int ob_count, typename P::E *__restrict__ Wp) {
     // element e -> (step, which, ob, lane, i)
     const int total = steps * 2 * ob_count * 64 * 8;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -313,25 +313,24 @@ __global__ void pack_layer_bf16_kernel(const float *__restrict__ W, int kind, in
         const int col = slot_feature(kind, step * 8 + i, lane >> 5);
         const int row = out_row(kind, ob * 32 + (lane & 31), out_dim);
         const float w = (col >= 0 && row >= 0) ? W[(size_t)row * in_dim + col] : 0.0f;
-        const __bf16 hi = (__bf16)w;
-        Wp[e] = which == 0 ? hi : (__bf16)(w - (float)hi);
+        const typename P::E hi = P::w_hi(w);
+        Wp[e] = which == 0 ? hi : P::w_lo(w, hi);
     }
 }
 
-struct SplitB {      // B operand of one 16-wide k-step: 8 values per lane, as hi and lo bf16
-    bf16x8 hi, lo;
+template <typename P>
+struct SplitT {      // B operand of one 16-wide k-step: 8 values per lane, as hi and lo pieces
+    typename P::V8 hi, lo;
 };
+typedef SplitT<Bf16x3> SplitB;
 
-__device__ __forceinline__ SplitB split8(const float (&v)[8]) {
-    SplitB o;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const __bf16 h = (__bf16)v[i];
-        o.hi[i] = h;
-        o.lo[i] = (__bf16)(v[i] - (float)h);
-    }
+template <typename P>
+__device__ __forceinline__ SplitT<P> split8t(const float (&v)[8]) {
+    SplitT<P> o;
+    P::split8(v, o.hi, o.lo);
     return o;
 }
+__device__ __forceinline__ SplitB split8(const float (&v)[8]) { return split8t<Bf16x3>(v); }
 
 #define OCC_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
@@ -367,15 +366,16 @@ __device__ __forceinline__ void load_step(bf16x8 (&ah)[OB], bf16x8 (&al)[OB], co
     }
 
 // relu(acc) -> the 16 split B operands of the next layer (2 per 32-feature block)
-__device__ __forceinline__ void relu_split(SplitB (&b)[2 * kOB], const f32x16 (&acc)[kOB]) {
+template <typename P>
+__device__ __forceinline__ void relu_split(SplitT<P> (&b)[2 * kOB], const f32x16 (&acc)[kOB]) {
 #pragma unroll
     for (int ob = 0; ob < kOB; ob++) {
 #pragma unroll
         for (int sub = 0; sub < 2; sub++) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = fmaxf(acc[ob][sub * 8 + i], 0.0f);
-            b[ob * 2 + sub] = split8(v);
+            for (int i = 0; i < 8; i++) v[i] = P::relu(acc[ob][sub * 8 + i]);
+            b[ob * 2 + sub] = split8t<P>(v);
         }
     }
 }
@@ -538,15 +538,19 @@ __device__ __forceinline__ void lds_bias(f32x16 (&acc)[OB], const float *aux, in
     }
 }
 
-__global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
+template <typename P>
+__global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     const float *__restrict__ mlp_in, const int32_t *__restrict__ in_rows /*nullable: input row of entry n*/, int64_t N_max,
     const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/, const float *__restrict__ pk,
-    const bf16x8 *__restrict__ pkh, float *__restrict__ raw) {
+    const typename P::V8 *__restrict__ pkh, float *__restrict__ raw) {
+    typedef typename P::V8 V8;
+    typedef SplitT<P> Split;
+    constexpr float kSx = P::kSx, kInvSx = 1.0f / P::kSx;
     const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
     if ((int64_t)blockIdx.x * 128 >= N) return;      // launches are sized for the worst case; uniform per workgroup
     // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read)
-    __shared__ __attribute__((aligned(16))) bf16x8 smem[kRingSlots * kChunkUnits + Aux::kTotal / 4];
-    bf16x8 *ring = smem;
+    __shared__ __attribute__((aligned(16))) V8 smem[kRingSlots * kChunkUnits + Aux::kTotal / 4];
+    V8 *ring = smem;
     float *aux = reinterpret_cast<float *>(smem + kRingSlots * kChunkUnits);
 
     const int lane = threadIdx.x & 63;
@@ -558,32 +562,33 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
     const int64_t nsrc = in_rows ? (int64_t)in_rows[nsrc0] : nsrc0;
 
     // ---- side data -> LDS, inputs -> registers (ordinary loads, before any DMA is in flight) ----
-    auto copy = [&](int dst, int64_t src, int count) {
-        for (int i = threadIdx.x; i < count; i += 256) aux[dst + i] = pk[src + i];
+    // (the biases of the MFMA layers travel in the activations' scale; the two VALU head rows and their biases do not)
+    auto copy = [&](int dst, int64_t src, int count, float scale) {
+        for (int i = threadIdx.x; i < count; i += 256) aux[dst + i] = pk[src + i] * scale;
     };
-    copy(Aux::kGeoL0B, Blob::kGeoL0B, 256);
-    for (int l = 0; l < 3; l++) copy(Aux::kGeoHB + l * 256, Blob::kGeoHW + l * Blob::kHiddenStride + wsz(kG_Hidden, kOB), 256);
-    copy(Aux::kGeoHeadB, Blob::kGeoHeadB, 64);
-    copy(Aux::kSigma, Blob::kSigmaW, 260);
-    copy(Aux::kRgbL0B, Blob::kRgbL0B, 256);
-    for (int l = 0; l < 3; l++) copy(Aux::kRgbHB + l * 256, Blob::kRgbHW + l * Blob::kHiddenStride + wsz(kG_Hidden, kOB), 256);
-    copy(Aux::kOut, Blob::kOutW, 772);
+    copy(Aux::kGeoL0B, Blob::kGeoL0B, 256, kSx);
+    for (int l = 0; l < 3; l++) copy(Aux::kGeoHB + l * 256, Blob::kGeoHW + l * Blob::kHiddenStride + wsz(kG_Hidden, kOB), 256, kSx);
+    copy(Aux::kGeoHeadB, Blob::kGeoHeadB, 64, kSx);
+    copy(Aux::kSigma, Blob::kSigmaW, 260, 1.0f);
+    copy(Aux::kRgbL0B, Blob::kRgbL0B, 256, kSx);
+    for (int l = 0; l < 3; l++) copy(Aux::kRgbHB + l * 256, Blob::kRgbHW + l * Blob::kHiddenStride + wsz(kG_Hidden, kOB), 256, kSx);
+    copy(Aux::kOut, Blob::kOutW, 772, 1.0f);
 
-    SplitB bx[kS_L0Geo];
+    Split bx[kS_L0Geo];
     {
         const float *src = mlp_in + nsrc * kInGeo + h * 34;
 #pragma unroll
         for (int s = 0; s < kS_L0Geo; s++) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = (s * 8 + i) < 34 ? src[s * 8 + i] : 0.0f;
-            bx[s] = split8(v);
+            for (int i = 0; i < 8; i++) v[i] = (s * 8 + i) < 34 ? P::sym(src[s * 8 + i] * kSx) : 0.0f;
+            bx[s] = split8t<P>(v);
         }
     }
     __syncthreads();
 
     // ---- weight stream: chunk g lives in ring slot g & 3 ----
-    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) bf16x8 *)ring;
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) V8 *)ring;
     auto issue = [&](int g) {      // this wave's quarter of chunk g: 4 x 1 KiB
 #pragma unroll
         for (int f = 0; f < 4; f++) {
@@ -602,24 +607,25 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   \
     __builtin_amdgcn_s_barrier();                                      \
     issue(g + 3);                                                      \
-    const bf16x8 *slot_ = ring + (g & (kRingSlots - 1)) * kChunkUnits; \
+    const V8 *slot_ = ring + (g & (kRingSlots - 1)) * kChunkUnits; \
     g++;
 
     // one 16-wide k-step per chunk, 8 output blocks
 #define OCC_LAYER_LDS8(STEPS, ACC, BOPS)                                                   \
     _Pragma("unroll") for (int s_ = 0; s_ < (STEPS); s_++) {                               \
         OCC_CHUNK_ENTER()                                                                  \
-        bf16x8 ah_[kOB], al_[kOB];                                                         \
+        V8 ah_[kOB], al_[kOB];                                                             \
         _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ah_[ob_] = slot_[ob_ * 64 + lane];         \
         _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) al_[ob_] = slot_[(kOB + ob_) * 64 + lane]; \
-        const SplitB &b_ = BOPS(s_);                                                       \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = OCC_MFMA_BF16(ah_[ob_], b_.hi, ACC[ob_]); \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = OCC_MFMA_BF16(ah_[ob_], b_.lo, ACC[ob_]); \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = OCC_MFMA_BF16(al_[ob_], b_.hi, ACC[ob_]); \
+        const Split &b_ = BOPS(s_);                                                        \
+        const V8 b3_ = P::third(b_.hi);                                                    \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.hi, ACC[ob_]); \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.lo, ACC[ob_]); \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(al_[ob_], b3_, ACC[ob_]);   \
     }
 
     f32x16 acc[kOB];
-    SplitB bact[2 * kOB];
+    Split bact[2 * kOB];
 
     // ---------------- geometry trunk ----------------
     lds_bias<kOB>(acc, aux + Aux::kGeoL0B, h);
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
                 for (int rr = 0; rr < 4; rr++) sacc = __fmaf_rn(w[rr], fmaxf(acc[kb][q * 4 + rr], 0.0f), sacc);
             }
         }
-        sigma = sacc + __shfl_xor(sacc, 32) + aux[Aux::kSigma + 256];
+        sigma = (sacc + __shfl_xor(sacc, 32)) * kInvSx + aux[Aux::kSigma + 256];
     }
     relu_split(bact, acc);
     // geometry head: 2 output blocks; a chunk carries 4 k-steps [step][hi|lo][ob][lane]
@@ -657,30 +663,31 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
         OCC_CHUNK_ENTER()
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const SplitB &b = bact[c * 4 + q];
-            bf16x8 ah[2], al[2];
+            const Split &b = bact[c * 4 + q];
+            const V8 b3 = P::third(b.hi);
+            V8 ah[2], al[2];
 #pragma unroll
             for (int ob = 0; ob < 2; ob++) {
                 ah[ob] = slot_[((q * 2 + 0) * 2 + ob) * 64 + lane];
                 al[ob] = slot_[((q * 2 + 1) * 2 + ob) * 64 + lane];
             }
 #pragma unroll
-            for (int ob = 0; ob < 2; ob++) geo[ob] = OCC_MFMA_BF16(ah[ob], b.hi, geo[ob]);
+            for (int ob = 0; ob < 2; ob++) geo[ob] = P::mfma(ah[ob], b.hi, geo[ob]);
 #pragma unroll
-            for (int ob = 0; ob < 2; ob++) geo[ob] = OCC_MFMA_BF16(ah[ob], b.lo, geo[ob]);
+            for (int ob = 0; ob < 2; ob++) geo[ob] = P::mfma(ah[ob], b.lo, geo[ob]);
 #pragma unroll
-            for (int ob = 0; ob < 2; ob++) geo[ob] = OCC_MFMA_BF16(al[ob], b.hi, geo[ob]);
+            for (int ob = 0; ob < 2; ob++) geo[ob] = P::mfma(al[ob], b3, geo[ob]);
         }
     }
-    SplitB bgeo[4];
+    Split bgeo[4];
 #pragma unroll
     for (int b = 0; b < 2; b++) {
 #pragma unroll
         for (int sub = 0; sub < 2; sub++) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = geo[b][sub * 8 + i];
-            bgeo[b * 2 + sub] = split8(v);
+            for (int i = 0; i < 8; i++) v[i] = P::sym(geo[b][sub * 8 + i]);
+            bgeo[b * 2 + sub] = split8t<P>(v);
         }
     }
 
@@ -710,7 +717,7 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_bf16x3_lds_kernel(
                 for (int rr = 0; rr < 4; rr++) sacc = __fmaf_rn(w[rr], fmaxf(acc[kb][q * 4 + rr], 0.0f), sacc);
             }
         }
-        rgb[c] = sacc + __shfl_xor(sacc, 32) + aux[Aux::kOut + 3 * kWidth + c];
+        rgb[c] = (sacc + __shfl_xor(sacc, 32)) * kInvSx + aux[Aux::kOut + 3 * kWidth + c];
     }
     if (h == 0 && n < N) {
         float *o = raw + n * 5;
@@ -763,14 +770,15 @@ OCC_API int64_t occnerf_canonical_mlp_packed_bf16_bytes(void) {
     return (occ::BlobH::kTotal + (int64_t)occ::kTailChunks * occ::kChunkUnits) * 16;   // + zero tail chunks
 }
 
-OCC_API int occnerf_canonical_mlp_pack_bf16(const float *const *h_W, void *packed_bf16, void *stream) {
+template <typename P>
+static int mlp_pack_split(const float *const *h_W, void *packed_split, void *stream) {
     using namespace occ;
-    OCC_REQUIRE(h_W && packed_bf16, "canonical_mlp_pack_bf16: null argument");
-    for (int i = 0; i < 10; i++) OCC_REQUIRE(h_W[i], "canonical_mlp_pack_bf16: layer %d missing", i);
+    OCC_REQUIRE(h_W && packed_split, "canonical_mlp_pack (split): null argument");
+    for (int i = 0; i < 10; i++) OCC_REQUIRE(h_W[i], "canonical_mlp_pack (split): layer %d missing", i);
     hipStream_t st = as_stream(stream);
-    __bf16 *base = reinterpret_cast<__bf16 *>(packed_bf16);
+    typename P::E *base = reinterpret_cast<typename P::E *>(packed_split);
     auto layer = [&](int li, int kind, int in_dim, int out_dim, int steps, int ob, int64_t off) {
-        hipLaunchKernelGGL(pack_layer_bf16_kernel, dim3(256), dim3(256), 0, st, h_W[li], kind, in_dim, out_dim,
+        hipLaunchKernelGGL(pack_layer_split_kernel<P>, dim3(256), dim3(256), 0, st, h_W[li], kind, in_dim, out_dim,
                            steps, ob, base + off * 8);
     };
     layer(0, kL0Geo, kInGeo, kWidth, kS_L0Geo, kOB, BlobH::kGeoL0);
@@ -778,7 +786,15 @@ OCC_API int occnerf_canonical_mlp_pack_bf16(const float *const *h_W, void *packe
     layer(4, kGeoHead, kWidth, 65, kS_Hidden, 2, BlobH::kGeoHead);
     layer(5, kL0Rgb, kInRgb, kWidth, kS_L0Rgb, kOB, BlobH::kRgbL0);
     for (int l = 0; l < 3; l++) layer(6 + l, kHidden, kWidth, kWidth, kS_Hidden, kOB, BlobH::kRgbH + l * BlobH::kHiddenStride);
-    return check_launch("canonical_mlp_pack_bf16");
+    return check_launch("canonical_mlp_pack (split)");
+}
+
+OCC_API int occnerf_canonical_mlp_pack_bf16(const float *const *h_W, void *packed_bf16, void *stream) {
+    return mlp_pack_split<occ::Bf16x3>(h_W, packed_bf16, stream);
+}
+
+OCC_API int occnerf_canonical_mlp_pack_f16(const float *const *h_W, void *packed_f16, void *stream) {
+    return mlp_pack_split<occ::F16x3>(h_W, packed_f16, stream);
 }
 
 static int mlp_bf16x3_launch(const float *mlp_in, const int32_t *in_rows, int64_t N_max, const int32_t *n_dev,
@@ -788,7 +804,7 @@ static int mlp_bf16x3_launch(const float *mlp_in, const int32_t *in_rows, int64_
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_bf16x3: N too large");
     const bf16x8 *pkh = reinterpret_cast<const bf16x8 *>(packed_bf16);
     if (variant == 0)
-        hipLaunchKernelGGL(canonical_mlp_bf16x3_lds_kernel, dim3((unsigned)blocks), dim3(256), 0,
+        hipLaunchKernelGGL(canonical_mlp_split_lds_kernel<Bf16x3>, dim3((unsigned)blocks), dim3(256), 0,
                            as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
     else
         hipLaunchKernelGGL(canonical_mlp_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0,
@@ -802,6 +818,21 @@ OCC_API int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const f
     if (N <= 0) return 0;
     OCC_REQUIRE(mlp_in && packed && packed_bf16 && raw, "canonical_mlp_bf16x3: null argument");
     return mlp_bf16x3_launch(mlp_in, nullptr, N, nullptr, packed, packed_bf16, raw, variant, stream);
+}
+
+/* The fp32-grade split (F16x3 above): same packed fp32 blob for biases / head rows, weights from occnerf_canonical_mlp_pack_f16.
+ * in_rows / n_dev nullable (all N_max rows, identity). */
+OCC_API int occnerf_canonical_mlp_f16x3(const float *mlp_in, const int32_t *in_rows, int64_t N_max, const int32_t *n_dev,
+                                        const float *packed, const void *packed_f16, float *raw, void *stream) {
+    using namespace occ;
+    if (N_max <= 0) return 0;
+    OCC_REQUIRE(mlp_in && packed && packed_f16 && raw, "canonical_mlp_f16x3: null argument");
+    OCC_REQUIRE(!in_rows || n_dev, "canonical_mlp_f16x3: a row list needs its device-side count");
+    const int64_t blocks = (N_max + 127) / 128;
+    OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_f16x3: N too large");
+    hipLaunchKernelGGL(canonical_mlp_split_lds_kernel<F16x3>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), mlp_in,
+                       in_rows, N_max, n_dev, packed, reinterpret_cast<const f16x8 *>(packed_f16), raw);
+    return check_launch("canonical_mlp_f16x3");
 }
 
 OCC_API int occnerf_canonical_mlp_bf16x3_rows(const float *mlp_in, const int32_t *in_rows, int64_t N_max,

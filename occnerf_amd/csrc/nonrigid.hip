@@ -16,6 +16,7 @@
 //
 // MFMA per wave: 80 + 3*256 + 336 + 256 = 1440 (algorithmic 1424).  Bound: fp32 MFMA.
 #include "common.h"
+#include "split.h"
 
 namespace occ {
 
@@ -232,8 +233,6 @@ __global__ __launch_bounds__(256, 2) void nonrigid_kernel(const float *xyz_in /*
 // weights streamed once per workgroup through an LDS ring by LDS-DMA.  A 16 KiB chunk holds two
 // 16-wide k-steps x {hi,lo} x 4 output blocks; 23 chunks per tile.
 // =======================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int kNrS_E = 3;                       // embedding: 18 slots per half -> 3 k-steps (6 pad)
 constexpr int kNrS_H = kNrW / 16;               // 8
 constexpr int kNrSteps = kNrS_E + 3 * kNrS_H + (kNrS_H + kNrS_E) + kNrS_H;   // 46
@@ -247,8 +246,9 @@ struct NrAux {      // floats in LDS
     static constexpr int kL0B = 0, kHB = 128, kSkipB = 512, kL5B = 640, kOut = 768, kTotal = 1156;
 };
 
-__global__ void nr_pack_bf16_kernel(const float *__restrict__ W, int kind, int in_dim, int steps,
-                                    __bf16 *__restrict__ Wp) {
+template <typename P>
+__global__ void nr_pack_split_kernel(const float *__restrict__ W, int kind, int in_dim, int steps,
+                                     typename P::E *__restrict__ Wp) {
     const int total = steps * 2 * kNrOB * 64 * 8;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int i = e & 7, lane = (e >> 3) & 63;
@@ -258,23 +258,20 @@ __global__ void nr_pack_bf16_kernel(const float *__restrict__ W, int kind, int i
         const int which = rest & 1, step = rest >> 1;
         const int col = nr_slot_feature(kind, step * 8 + i, lane >> 5);
         const float w = col >= 0 ? W[(size_t)(ob * 32 + (lane & 31)) * in_dim + col] : 0.0f;
-        const __bf16 hi = (__bf16)w;
-        Wp[e] = which == 0 ? hi : (__bf16)(w - (float)hi);
+        const typename P::E hi = P::w_hi(w);
+        Wp[e] = which == 0 ? hi : P::w_lo(w, hi);
     }
 }
 
-struct NrSplit {
-    bf16x8 hi, lo;
+template <typename P>
+struct NrSplitT {
+    typename P::V8 hi, lo;
 };
 
-__device__ __forceinline__ NrSplit nr_split8(const float (&v)[8]) {
-    NrSplit o;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const __bf16 h = (__bf16)v[i];
-        o.hi[i] = h;
-        o.lo[i] = (__bf16)(v[i] - (float)h);
-    }
+template <typename P>
+__device__ __forceinline__ NrSplitT<P> nr_split8(const float (&v)[8]) {
+    NrSplitT<P> o;
+    P::split8(v, o.hi, o.lo);
     return o;
 }
 
@@ -290,16 +287,18 @@ __device__ __forceinline__ void nr_glds16(const void *gbase, unsigned lane_off, 
                  : "memory");
 }
 
-#define NR_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-
-__global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N_max,
+template <typename P>
+__global__ __launch_bounds__(256, 1) void nonrigid_split_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N_max,
                                                                  const int32_t *__restrict__ rows /*nullable: sample of entry n*/,
                                                                  const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/,
                                                                  const float *__restrict__ pk,
-                                                                 const bf16x8 *__restrict__ pkh, NrParams prm,
+                                                                 const typename P::V8 *__restrict__ pkh, NrParams prm,
                                                                  float *xyz_out) {
-    __shared__ __attribute__((aligned(16))) bf16x8 smem[kNrRing * kNrChunkUnits + NrAux::kTotal / 4];
-    bf16x8 *ring = smem;
+    typedef typename P::V8 V8;
+    typedef NrSplitT<P> NrSplit;
+    constexpr float kSx = P::kSx, kInvSx = 1.0f / P::kSx;
+    __shared__ __attribute__((aligned(16))) V8 smem[kNrRing * kNrChunkUnits + NrAux::kTotal / 4];
+    V8 *ring = smem;
     float *aux = reinterpret_cast<float *>(smem + kNrRing * kNrChunkUnits);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -310,14 +309,15 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xy
     const int64_t nsrc0 = n < N ? n : N - 1;
     const int64_t nsrc = rows ? (int64_t)rows[nsrc0] : nsrc0;      // (with a row list the offsets are written back to the listed rows)
 
-    auto copy = [&](int dst, int64_t src, int count) {
-        for (int i = threadIdx.x; i < count; i += 256) aux[dst + i] = pk[src + i];
+    // (the biases of the MFMA layers travel in the activations' scale; the output rows and their bias do not)
+    auto copy = [&](int dst, int64_t src, int count, float scale) {
+        for (int i = threadIdx.x; i < count; i += 256) aux[dst + i] = pk[src + i] * scale;
     };
-    copy(NrAux::kL0B, NrBlob::kL0B, 128);
-    for (int l = 0; l < 3; l++) copy(NrAux::kHB + l * 128, NrBlob::kHW + l * NrBlob::kHStride + nr_wsz(kG_H), 128);
-    copy(NrAux::kSkipB, NrBlob::kSkipB, 128);
-    copy(NrAux::kL5B, NrBlob::kL5B, 128);
-    copy(NrAux::kOut, NrBlob::kOutW, 388);
+    copy(NrAux::kL0B, NrBlob::kL0B, 128, kSx);
+    for (int l = 0; l < 3; l++) copy(NrAux::kHB + l * 128, NrBlob::kHW + l * NrBlob::kHStride + nr_wsz(kG_H), 128, kSx);
+    copy(NrAux::kSkipB, NrBlob::kSkipB, 128, kSx);
+    copy(NrAux::kL5B, NrBlob::kL5B, 128, kSx);
+    copy(NrAux::kOut, NrBlob::kOutW, 388, 1.0f);
 
     const float p[3] = {xyz_in[nsrc * 3], xyz_in[nsrc * 3 + 1], xyz_in[nsrc * 3 + 2]};
     NrSplit be[kNrS_E];      // embedding operands: slots 0..17 of this half, 6 zero pads
@@ -342,13 +342,13 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xy
         for (int s = 0; s < kNrS_E; s++) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = e[s * 8 + i];
-            be[s] = nr_split8(v);
+            for (int i = 0; i < 8; i++) v[i] = e[s * 8 + i] * kSx;
+            be[s] = nr_split8<P>(v);
         }
     }
     __syncthreads();
 
-    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) bf16x8 *)ring;
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) V8 *)ring;
     auto issue = [&](int g) {
 #pragma unroll
         for (int f = 0; f < 4; f++) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xy
 
     // The k-steps of the whole network form one stream: step index `st` (compile-time after
     // unrolling) -> chunk st/2, half st%2.  Entering a new chunk = counted wait + barrier + refill.
-    const bf16x8 *slot = ring;
+    const V8 *slot = ring;
 #define NR_STEP(ST, ACC, BSPLIT)                                                                   \
     {                                                                                              \
         if (((ST) & 1) == 0) {                                                                     \
@@ -372,14 +372,15 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xy
             issue((ST) / 2 + 3);                                                                   \
             slot = ring + (((ST) / 2) & (kNrRing - 1)) * kNrChunkUnits;                            \
         }                                                                                          \
-        const bf16x8 *st_ = slot + ((ST) & 1) * kNrStepUnits;                                      \
-        bf16x8 ah_[kNrOB], al_[kNrOB];                                                             \
+        const V8 *st_ = slot + ((ST) & 1) * kNrStepUnits;                                          \
+        V8 ah_[kNrOB], al_[kNrOB];                                                                 \
         _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ah_[ob_] = st_[ob_ * 64 + lane];   \
         _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) al_[ob_] = st_[(kNrOB + ob_) * 64 + lane]; \
         const NrSplit &b_ = (BSPLIT);                                                              \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ACC[ob_] = NR_MFMA_BF16(ah_[ob_], b_.hi, ACC[ob_]); \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ACC[ob_] = NR_MFMA_BF16(ah_[ob_], b_.lo, ACC[ob_]); \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ACC[ob_] = NR_MFMA_BF16(al_[ob_], b_.hi, ACC[ob_]); \
+        const V8 b3_ = P::third(b_.hi);                                                            \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.hi, ACC[ob_]); \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.lo, ACC[ob_]); \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < kNrOB; ob_++) ACC[ob_] = P::mfma(al_[ob_], b3_, ACC[ob_]);   \
     }
 #define NR_BIAS(OFF)                                                                               \
     {                                                                                              \
@@ -395,8 +396,8 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xy
     _Pragma("unroll") for (int ob = 0; ob < kNrOB; ob++) {                                         \
         _Pragma("unroll") for (int sub = 0; sub < 2; sub++) {                                      \
             float v[8];                                                                            \
-            _Pragma("unroll") for (int i = 0; i < 8; i++) v[i] = fmaxf(acc[ob][sub * 8 + i], 0.0f); \
-            bact[ob * 2 + sub] = nr_split8(v);                                                     \
+            _Pragma("unroll") for (int i = 0; i < 8; i++) v[i] = P::relu(acc[ob][sub * 8 + i]);    \
+            bact[ob * 2 + sub] = nr_split8<P>(v);                                                  \
         }                                                                                          \
     }
 
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void nonrigid_bf16x3_kernel(const float *xy
                 for (int rr = 0; rr < 4; rr++) sacc = __fmaf_rn(w[rr], fmaxf(acc[kb][q * 4 + rr], 0.0f), sacc);
             }
         }
-        off[c] = sacc + __shfl_xor(sacc, 32) + aux[NrAux::kOut + 3 * kNrW + c];
+        off[c] = (sacc + __shfl_xor(sacc, 32)) * kInvSx + aux[NrAux::kOut + 3 * kNrW + c];
     }
     if (h == 0 && n < N) {
 #pragma unroll
@@ -484,15 +485,16 @@ OCC_API int64_t occnerf_nonrigid_packed_bf16_bytes(void) {
     return ((int64_t)occ::kNrChunks + occ::kNrRing - 1) * occ::kNrChunkUnits * 16;     // + read-ahead tail
 }
 
-OCC_API int occnerf_nonrigid_pack_bf16(const float *const *h_W, void *packed_bf16, void *stream) {
+template <typename P>
+static int nr_pack_split(const float *const *h_W, void *packed_split, void *stream) {
     using namespace occ;
-    OCC_REQUIRE(h_W && packed_bf16, "nonrigid_pack_bf16: null argument");
-    for (int i = 0; i < 6; i++) OCC_REQUIRE(h_W[i], "nonrigid_pack_bf16: layer %d missing", i);
+    OCC_REQUIRE(h_W && packed_split, "nonrigid_pack (split): null argument");
+    for (int i = 0; i < 6; i++) OCC_REQUIRE(h_W[i], "nonrigid_pack (split): layer %d missing", i);
     hipStream_t st = as_stream(stream);
-    __bf16 *base = reinterpret_cast<__bf16 *>(packed_bf16);
+    typename P::E *base = reinterpret_cast<typename P::E *>(packed_split);
     int step = 0;
     auto layer = [&](int li, int kind, int in_dim, int steps) {
-        hipLaunchKernelGGL(nr_pack_bf16_kernel, dim3(64), dim3(256), 0, st, h_W[li], kind, in_dim, steps,
+        hipLaunchKernelGGL(nr_pack_split_kernel<P>, dim3(64), dim3(256), 0, st, h_W[li], kind, in_dim, steps,
                            base + (size_t)step * kNrStepUnits * 8);
         step += steps;
     };
@@ -500,43 +502,63 @@ OCC_API int occnerf_nonrigid_pack_bf16(const float *const *h_W, void *packed_bf1
     for (int l = 0; l < 3; l++) layer(1 + l, kNrHidden, kNrW, kNrS_H);
     layer(4, kNrSkip, kNrW + kEmb, kNrS_H + kNrS_E);
     layer(5, kNrHidden, kNrW, kNrS_H);
-    return check_launch("nonrigid_pack_bf16");
+    return check_launch("nonrigid_pack (split)");
 }
 
-OCC_API int occnerf_nonrigid_bf16x3(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
-                                    const float *W0, const float *b0, float *packed, const void *packed_bf16,
-                                    float *xyz_out, void *stream) {
+// xyz_in may alias xyz_out; rows / n_dev nullable (all N_max samples)
+template <typename P>
+static int nr_split_launch(const float *xyz_in, int64_t N_max, const int32_t *rows, const int32_t *n_dev, const float *cond,
+                           const float *h_hann, const float *W0, const float *b0, float *packed, const void *packed_split,
+                           float *xyz_out, void *stream, const char *what) {
     using namespace occ;
-    if (N <= 0) return 0;
-    OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && packed_bf16 && xyz_out,
-                "nonrigid_bf16x3: null argument");
-    hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(nr_fold_bias_kernel, dim3(1), dim3(128), 0, st, W0, b0, cond, packed + NrBlob::kL0B);
-    NrParams prm;
-    for (int i = 0; i < 6; i++) prm.hann[i] = h_hann[i];
-    const int64_t blocks = (N + 127) / 128;
-    OCC_REQUIRE(blocks < (1ll << 31), "nonrigid_bf16x3: N too large");
-    hipLaunchKernelGGL(nonrigid_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N, nullptr, nullptr, packed,
-                       reinterpret_cast<const bf16x8 *>(packed_bf16), prm, xyz_out);
-    return check_launch("nonrigid_bf16x3");
-}
-
-OCC_API int occnerf_nonrigid_bf16x3_rows(float *xyz, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
-                                         const float *cond, const float *h_hann, const float *W0, const float *b0,
-                                         float *packed, const void *packed_bf16, void *stream) {
-    using namespace occ;
-    if (N_max <= 0) return 0;
-    OCC_REQUIRE(xyz && rows && n_dev && cond && h_hann && W0 && b0 && packed && packed_bf16,
-                "nonrigid_bf16x3_rows: null argument");
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(nr_fold_bias_kernel, dim3(1), dim3(128), 0, st, W0, b0, cond, packed + NrBlob::kL0B);
     NrParams prm;
     for (int i = 0; i < 6; i++) prm.hann[i] = h_hann[i];
     const int64_t blocks = (N_max + 127) / 128;
-    OCC_REQUIRE(blocks < (1ll << 31), "nonrigid_bf16x3_rows: N too large");
-    hipLaunchKernelGGL(nonrigid_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz, N_max, rows, n_dev, packed,
-                       reinterpret_cast<const bf16x8 *>(packed_bf16), prm, xyz);
-    return check_launch("nonrigid_bf16x3_rows");
+    OCC_REQUIRE(blocks < (1ll << 31), "%s: N too large", what);
+    hipLaunchKernelGGL(nonrigid_split_kernel<P>, dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N_max, rows, n_dev, packed,
+                       reinterpret_cast<const typename P::V8 *>(packed_split), prm, xyz_out);
+    return check_launch(what);
+}
+
+OCC_API int occnerf_nonrigid_pack_bf16(const float *const *h_W, void *packed_bf16, void *stream) {
+    return nr_pack_split<occ::Bf16x3>(h_W, packed_bf16, stream);
+}
+
+OCC_API int occnerf_nonrigid_pack_f16(const float *const *h_W, void *packed_f16, void *stream) {
+    return nr_pack_split<occ::F16x3>(h_W, packed_f16, stream);
+}
+
+OCC_API int occnerf_nonrigid_bf16x3(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,
+                                    const float *W0, const float *b0, float *packed, const void *packed_bf16,
+                                    float *xyz_out, void *stream) {
+    if (N <= 0) return 0;
+    OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && packed_bf16 && xyz_out,
+                "nonrigid_bf16x3: null argument");
+    return nr_split_launch<occ::Bf16x3>(xyz_in, N, nullptr, nullptr, cond, h_hann, W0, b0, packed, packed_bf16, xyz_out, stream,
+                                        "nonrigid_bf16x3");
+}
+
+OCC_API int occnerf_nonrigid_bf16x3_rows(float *xyz, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
+                                         const float *cond, const float *h_hann, const float *W0, const float *b0,
+                                         float *packed, const void *packed_bf16, void *stream) {
+    if (N_max <= 0) return 0;
+    OCC_REQUIRE(xyz && rows && n_dev && cond && h_hann && W0 && b0 && packed && packed_bf16,
+                "nonrigid_bf16x3_rows: null argument");
+    return nr_split_launch<occ::Bf16x3>(xyz, N_max, rows, n_dev, cond, h_hann, W0, b0, packed, packed_bf16, xyz, stream,
+                                        "nonrigid_bf16x3_rows");
+}
+
+/* The fp32-grade split (split.h F16x3).  rows / n_dev nullable: all N_max samples; xyz_in may alias xyz_out. */
+OCC_API int occnerf_nonrigid_f16x3(const float *xyz_in, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
+                                   const float *cond, const float *h_hann, const float *W0, const float *b0, float *packed,
+                                   const void *packed_f16, float *xyz_out, void *stream) {
+    if (N_max <= 0) return 0;
+    OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && packed_f16 && xyz_out, "nonrigid_f16x3: null argument");
+    OCC_REQUIRE(!rows || n_dev, "nonrigid_f16x3: a row list needs its device-side count");
+    return nr_split_launch<occ::F16x3>(xyz_in, N_max, rows, n_dev, cond, h_hann, W0, b0, packed, packed_f16, xyz_out, stream,
+                                       "nonrigid_f16x3");
 }
 
 OCC_API int occnerf_nonrigid(const float *xyz_in, int64_t N, const float *cond, const float *h_hann,

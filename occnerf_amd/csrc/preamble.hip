@@ -129,6 +129,168 @@ __global__ __launch_bounds__(1024) void pose_motion_bases_kernel(PoseMlp mlp, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of pose_motion_bases_kernel w.r.t. the pose-refiner MLP (training step, SURVEY 8(f) rows 1 + 4): given
+// dL/dRs[24,3,3] and dL/dTs[24,3] (what the warp kernel's backward hands over), the gradients of the five Linear layers.
+// torch autograd spends ~460 launches of 2-5 us on this chain per step (inverse, 8 levels of indexed forward kinematics,
+// Rodrigues as ~25 elementwise ops, five batch-1 layers); it is < 1 MFLOP.  One workgroup: the forward is recomputed in
+// LDS (62 us, nothing to save between the passes), then
+//   f = C Ginv (C = cnl_gtfms):    dAi = C3^T dRs,  dti = C3^T dTs
+//   Ginv = [A^-1, -A^-1 T]:        dAi -= dti (x) T,  dT = -Ai^T dti,  dA = -Ai^T dAi Ai^T
+//   G_i = G_p L_i (reverse order): dRl_i = Rg_p^T dRg_i,  dRg_p += dRg_i Rl_i^T + dTg_i (x) Tl_i,  dTg_p += dTg_i
+//   Rl_j = dst_R_j Rod(r_j):       dRod = dst_R_j^T dRl_j,  dr_j = J_Rod(r_j)^T dRod   (theta = sqrt(1e-5 + |r|^2))
+//   five layers, batch 1:          dW_l = dz_l (x) h_l,  db_l = dz_l,  dz_{l-1} = (W_l^T dz_l) . [h_l > 0]
+// ---------------------------------------------------------------------------------------------------------------------
+struct PoseGrads {
+    float *dW[5];
+    float *db[5];
+};
+
+// dz_prev[k] = [h_prev[k] > 0] * sum_j W[j,k] dz[j]   (k < in_dim, j < out_dim; `mask`: apply the ReLU mask of h_prev);
+// dW[j,k] = dz[j] * h_prev[k], db[j] = dz[j].  All 1024 threads; part[] is 4 x 256 floats of LDS.
+__device__ __forceinline__ void dense_layer_backward(const float *__restrict__ W, int in_dim, int out_dim, const float *dz,
+                                                     const float *h_prev, bool mask, float *dz_prev, float *part,
+                                                     float *__restrict__ dW, float *__restrict__ db) {
+    const int t = threadIdx.x;
+    for (int e = t; e < out_dim * in_dim; e += blockDim.x) dW[e] = dz[e / in_dim] * h_prev[e % in_dim];
+    if (t < out_dim) db[t] = dz[t];
+    if (dz_prev) {
+        const int k = t & 255, q = t >> 8;                    // 4 groups of rows per column
+        float s = 0.0f;
+        if (k < in_dim)
+            for (int j = q; j < out_dim; j += 4) s = __fmaf_rn(W[(size_t)j * in_dim + k], dz[j], s);
+        part[q * 256 + k] = s;
+        __syncthreads();
+        if (t < in_dim) {
+            const float v = (part[t] + part[256 + t]) + (part[512 + t] + part[768 + t]);
+            dz_prev[t] = (!mask || h_prev[t] > 0.0f) ? v : 0.0f;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void pose_motion_bases_backward_kernel(PoseMlp mlp, const float *__restrict__ posevec,
+                                                                          const float *__restrict__ dst_Rs,
+                                                                          const float *__restrict__ dst_Ts,
+                                                                          const float *__restrict__ cnl_gtfms,
+                                                                          const float *__restrict__ dRs, const float *__restrict__ dTs,
+                                                                          PoseGrads out) {
+    __shared__ float h[5][kPoseW];                        // h[0] = posevec (69), h[1..4] = the four ReLU outputs
+    __shared__ float rvec[72], drvec[72];
+    __shared__ float Rl[kBones][9], Tl[kBones][3], Rg[kBones][9], Tg[kBones][3];
+    __shared__ float dRg[kBones][9], dTg[kBones][3], dRl[kBones][9];
+    __shared__ float dza[kPoseW], dzb[kPoseW], part[4 * 256];
+    const int t = threadIdx.x;
+    // ---- forward, as pose_motion_bases_kernel (refine on) ----
+    if (t < kBones * 9) Rl[t / 9][t % 9] = dst_Rs[t];
+    if (t < kBones * 3) Tl[t / 3][t % 3] = dst_Ts[t];
+    if (t < 69) h[0][t] = posevec[t];
+    __syncthreads();
+    dense_layer(mlp.W[0], mlp.b[0], 69, kPoseW, h[0], h[1], true);
+    dense_layer(mlp.W[1], mlp.b[1], kPoseW, kPoseW, h[1], h[2], true);
+    dense_layer(mlp.W[2], mlp.b[2], kPoseW, kPoseW, h[2], h[3], true);
+    dense_layer(mlp.W[3], mlp.b[3], kPoseW, kPoseW, h[3], h[4], true);
+    dense_layer(mlp.W[4], mlp.b[4], kPoseW, 69, h[4], rvec, false);
+    if (t < kBones - 1) {
+        const float rx = rvec[t * 3], ry = rvec[t * 3 + 1], rz = rvec[t * 3 + 2];
+        const float theta = sqrtf(1e-5f + (rx * rx + ry * ry + rz * rz));
+        const float x = rx / theta, y = ry / theta, z = rz / theta;
+        const float c = cosf(theta), s = sinf(theta), oc = 1.0f - c;
+        const float C[9] = {x * x + (1.0f - x * x) * c, x * y * oc - z * s, x * z * oc + y * s,
+                            x * y * oc + z * s, y * y + (1.0f - y * y) * c, y * z * oc - x * s,
+                            x * z * oc - y * s, y * z * oc + x * s, z * z + (1.0f - z * z) * c};
+        float A[9], O[9];
+        for (int e = 0; e < 9; e++) A[e] = Rl[t + 1][e];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) O[i * 3 + j] = A[i * 3] * C[j] + A[i * 3 + 1] * C[3 + j] + A[i * 3 + 2] * C[6 + j];
+        for (int e = 0; e < 9; e++) Rl[t + 1][e] = O[e];
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (int e = 0; e < 9; e++) Rg[0][e] = Rl[0][e];
+        for (int e = 0; e < 3; e++) Tg[0][e] = Tl[0][e];
+        for (int i = 1; i < kBones; i++) {
+            const int p = c_smpl_parent[i];
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++)
+                    Rg[i][r * 3 + c] = Rg[p][r * 3] * Rl[i][c] + Rg[p][r * 3 + 1] * Rl[i][3 + c] + Rg[p][r * 3 + 2] * Rl[i][6 + c];
+                Tg[i][r] = Rg[p][r * 3] * Tl[i][0] + Rg[p][r * 3 + 1] * Tl[i][1] + Rg[p][r * 3 + 2] * Tl[i][2] + Tg[p][r];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- backward of f = C [A^-1, -A^-1 T] ----
+    if (t < kBones) {
+        const float *a = Rg[t];
+        const float c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+        const float id = 1.0f / (a[0] * c00 + a[1] * c01 + a[2] * c02);
+        const float Ai[9] = {c00 * id, (a[2] * a[7] - a[1] * a[8]) * id, (a[1] * a[5] - a[2] * a[4]) * id,
+                             c01 * id, (a[0] * a[8] - a[2] * a[6]) * id, (a[2] * a[3] - a[0] * a[5]) * id,
+                             c02 * id, (a[1] * a[6] - a[0] * a[7]) * id, (a[0] * a[4] - a[1] * a[3]) * id};
+        const float *G = cnl_gtfms + t * 16;
+        float dAi[9], dti[3];
+        for (int r = 0; r < 3; r++) {                         // C3^T dRs, C3^T dTs
+            for (int c = 0; c < 3; c++)
+                dAi[r * 3 + c] = G[r] * dRs[t * 9 + c] + G[4 + r] * dRs[t * 9 + 3 + c] + G[8 + r] * dRs[t * 9 + 6 + c];
+            dti[r] = G[r] * dTs[t * 3] + G[4 + r] * dTs[t * 3 + 1] + G[8 + r] * dTs[t * 3 + 2];
+        }
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) dAi[r * 3 + c] -= dti[r] * Tg[t][c];            // ti = -Ai T
+            dTg[t][r] = -(Ai[r] * dti[0] + Ai[3 + r] * dti[1] + Ai[6 + r] * dti[2]);
+        }
+        float M[9];                                           // dA = -Ai^T dAi Ai^T
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) M[r * 3 + c] = Ai[r] * dAi[c] + Ai[3 + r] * dAi[3 + c] + Ai[6 + r] * dAi[6 + c];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) dRg[t][r * 3 + c] = -(M[r * 3] * Ai[c * 3] + M[r * 3 + 1] * Ai[c * 3 + 1] + M[r * 3 + 2] * Ai[c * 3 + 2]);
+    }
+    __syncthreads();
+    // ---- forward kinematics, reverse order ----
+    if (t == 0) {
+        for (int i = kBones - 1; i >= 1; i--) {
+            const int p = c_smpl_parent[i];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) {
+                    dRl[i][r * 3 + c] = Rg[p][r] * dRg[i][c] + Rg[p][3 + r] * dRg[i][3 + c] + Rg[p][6 + r] * dRg[i][6 + c];
+                    dRg[p][r * 3 + c] += dRg[i][r * 3] * Rl[i][c * 3] + dRg[i][r * 3 + 1] * Rl[i][c * 3 + 1] +
+                                         dRg[i][r * 3 + 2] * Rl[i][c * 3 + 2] + dTg[i][r] * Tl[i][c];
+                }
+            for (int r = 0; r < 3; r++) dTg[p][r] += dTg[i][r];
+        }
+    }
+    __syncthreads();
+    // ---- corrected rotation + Rodrigues ----
+    if (t < 72) drvec[t] = 0.0f;
+    __syncthreads();
+    if (t < kBones - 1) {
+        const float *A = dst_Rs + (t + 1) * 9;
+        float g[9];                                            // dRod = dst_R^T dRl
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) g[r * 3 + c] = A[r] * dRl[t + 1][c] + A[3 + r] * dRl[t + 1][3 + c] + A[6 + r] * dRl[t + 1][6 + c];
+        const float rx = rvec[t * 3], ry = rvec[t * 3 + 1], rz = rvec[t * 3 + 2];
+        const float theta = sqrtf(1e-5f + (rx * rx + ry * ry + rz * rz));
+        const float x = rx / theta, y = ry / theta, z = rz / theta;
+        const float c = cosf(theta), s = sinf(theta), oc = 1.0f - c;
+        const float dx = g[0] * (2.0f * x * oc) + (g[1] + g[3]) * (y * oc) + (g[2] + g[6]) * (z * oc) + (g[7] - g[5]) * s;
+        const float dy = g[4] * (2.0f * y * oc) + (g[1] + g[3]) * (x * oc) + (g[5] + g[7]) * (z * oc) + (g[2] - g[6]) * s;
+        const float dz = g[8] * (2.0f * z * oc) + (g[2] + g[6]) * (x * oc) + (g[5] + g[7]) * (y * oc) + (g[3] - g[1]) * s;
+        const float dc = g[0] * (1.0f - x * x) + g[4] * (1.0f - y * y) + g[8] * (1.0f - z * z) -
+                         ((g[1] + g[3]) * (x * y) + (g[2] + g[6]) * (x * z) + (g[5] + g[7]) * (y * z));
+        const float ds = (g[3] - g[1]) * z + (g[2] - g[6]) * y + (g[7] - g[5]) * x;
+        const float dtheta = (ds * c - dc * s) - (dx * rx + dy * ry + dz * rz) / (theta * theta);
+        drvec[t * 3] = dx / theta + dtheta * rx / theta;
+        drvec[t * 3 + 1] = dy / theta + dtheta * ry / theta;
+        drvec[t * 3 + 2] = dz / theta + dtheta * rz / theta;
+    }
+    __syncthreads();
+    // ---- the five layers ----
+    dense_layer_backward(mlp.W[4], kPoseW, 69, drvec, h[4], true, dza, part, out.dW[4], out.db[4]);
+    dense_layer_backward(mlp.W[3], kPoseW, kPoseW, dza, h[3], true, dzb, part, out.dW[3], out.db[3]);
+    dense_layer_backward(mlp.W[2], kPoseW, kPoseW, dzb, h[2], true, dza, part, out.dW[2], out.db[2]);
+    dense_layer_backward(mlp.W[1], kPoseW, kPoseW, dza, h[1], true, dzb, part, out.dW[1], out.db[1]);
+    dense_layer_backward(mlp.W[0], 69, kPoseW, dzb, h[0], false, nullptr, part, out.dW[0], out.db[0]);
+}
+
 constexpr int kMaxVolCh = 32;
 
 __global__ __launch_bounds__(256) void prior_softmax_kernel(const float *__restrict__ dec, const float *__restrict__ prior,
@@ -192,6 +354,30 @@ OCC_API int occnerf_pose_motion_bases(const float *const *h_W, const float *cons
     hipLaunchKernelGGL(pose_motion_bases_kernel, dim3(1), dim3(1024), 0, as_stream(stream), mlp, posevec, refine, dst_Rs, dst_Ts,
                        cnl_gtfms, Rs, Ts);
     return check_launch("pose_motion_bases");
+}
+
+/* Gradients of the pose refiner's five Linear layers from dL/dRs[24,3,3], dL/dTs[24,3] (the motion bases' cotangents);
+ * h_dW[l] / h_db[l]: device buffers shaped like the layers' weights / biases, overwritten.  Refinement on (before the
+ * kick-in iteration the refiner does not take part in the graph). */
+OCC_API int occnerf_pose_motion_bases_backward(const float *const *h_W, const float *const *h_b, const float *posevec,
+                                               const float *dst_Rs, const float *dst_Ts, const float *cnl_gtfms,
+                                               const float *dRs, const float *dTs, float *const *h_dW, float *const *h_db,
+                                               void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(h_W && h_b && posevec && dst_Rs && dst_Ts && cnl_gtfms && dRs && dTs && h_dW && h_db,
+                "pose_motion_bases_backward: null argument");
+    PoseMlp mlp;
+    PoseGrads out;
+    for (int l = 0; l < 5; l++) {
+        OCC_REQUIRE(h_W[l] && h_b[l] && h_dW[l] && h_db[l], "pose_motion_bases_backward: layer %d missing", l);
+        mlp.W[l] = h_W[l];
+        mlp.b[l] = h_b[l];
+        out.dW[l] = h_dW[l];
+        out.db[l] = h_db[l];
+    }
+    hipLaunchKernelGGL(pose_motion_bases_backward_kernel, dim3(1), dim3(1024), 0, as_stream(stream), mlp, posevec, dst_Rs, dst_Ts,
+                       cnl_gtfms, dRs, dTs, out);
+    return check_launch("pose_motion_bases_backward");
 }
 
 OCC_API int occnerf_prior_softmax(const float *decoded, const float *prior, int32_t C, int64_t V, float *vol, void *stream) {

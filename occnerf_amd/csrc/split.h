@@ -1,0 +1,71 @@
+// Precision policies of the split-operand MLP kernels (mlp.hip, nonrigid.hip): how an fp32 operand is cut into two 16-bit
+// pieces for the bf16 / fp16 matrix pipe and what the three products are.
+#pragma once
+
+#include "common.h"
+
+namespace occ {
+
+typedef float split_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ---- precision policies of the split kernels ----------------------------------------------------------------------
+// Bf16x3: hi = bf16(v), lo = bf16(v - hi): 16 significand bits per operand, 2^-17 of relative residue (opt-in 'bf16x3';
+// meets the 1e-4 pixel gate on the random-init checkpoint only).
+// F16x3 (round 5, 'f16x3'): the fp32-grade split.  fp16 carries 11 significand bits, so hi + lo = 22 bits and each dropped
+// quantity is 2^-22 relative (fp32 itself: 2^-24) -- but only while the pieces stay NORMAL fp16 numbers, which is what the
+// scales are for (measured first: tools/mfma_f16_probe.hip -- v_mfma_f32_32x32x16_f16 preserves subnormal inputs of both
+// operands, and its fp32 accumulation over K = 256 is 2.6x closer to float64 than an fmaf chain):
+//   activations travel scaled by kSx = 16 (exact: biases are scaled at the LDS copy, the two head dot products divide by
+//     it): xh = f16(16 x), xl = f16(16 x - xh).  Full 22 bits for 2^-7 <= |x| < 4094; smaller values degrade to an ABSOLUTE
+//     error of 2^-25 / 16 = 1.9e-9 (subnormal xl), nothing is flushed; larger ones saturate at 65504 / 16 (the ReLU is a
+//     v_med3 with that bound: the documented domain of this mode -- hidden activations below 4 094);
+//   weights: Wh = f16(W), and the lo piece is stored SCALED, Wl' = f16((W - Wh) 2^11), so that it is a normal number for
+//     every |W| >= 2^-14; its product uses xh 2^-11 (a packed-half multiply per k-step, exact for xh >= 2^-3):
+//       acc += Wh xh + Wh xl + Wl' (xh 2^-11)          -- one accumulator, three MFMAs, as bf16x3.
+struct Bf16x3 {
+    typedef bf16x8 V8;
+    typedef __bf16 E;
+    static constexpr float kSx = 1.0f;
+    static __device__ __forceinline__ split_f32x16 mfma(V8 a, V8 b, split_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ E w_hi(float w) { return (E)w; }
+    static __device__ __forceinline__ E w_lo(float w, E hi) { return (E)(w - (float)hi); }
+    static __device__ __forceinline__ void split8(const float (&v)[8], V8 &hi, V8 &lo) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const E h = (E)v[i];
+            hi[i] = h;
+            lo[i] = (E)(v[i] - (float)h);
+        }
+    }
+    static __device__ __forceinline__ V8 third(V8 xh) { return xh; }
+    static __device__ __forceinline__ float relu(float a) { return fmaxf(a, 0.0f); }
+    static __device__ __forceinline__ float sym(float a) { return a; }
+};
+struct F16x3 {
+    typedef f16x8 V8;
+    typedef _Float16 E;
+    static constexpr float kSx = 16.0f;
+    static __device__ __forceinline__ split_f32x16 mfma(V8 a, V8 b, split_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ E w_hi(float w) { return (E)w; }
+    static __device__ __forceinline__ E w_lo(float w, E hi) { return (E)((w - (float)hi) * 2048.0f); }
+    static __device__ __forceinline__ void split8(const float (&v)[8], V8 &hi, V8 &lo) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const E h = (E)v[i];
+            hi[i] = h;
+            lo[i] = (E)(v[i] - (float)h);
+        }
+    }
+    static __device__ __forceinline__ V8 third(V8 xh) { return xh * (E)0.00048828125f; }      // 2^-11
+    static __device__ __forceinline__ float relu(float a) { return __builtin_amdgcn_fmed3f(a, 0.0f, 65504.0f); }
+    static __device__ __forceinline__ float sym(float a) { return __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f); }
+};
+
+
+}  // namespace occ

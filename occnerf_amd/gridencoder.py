@@ -80,7 +80,12 @@ class _GridEncode(Function):
     def backward(ctx, grad):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, Cc, L, S, H, gridtype, interpolation = ctx.dims
-        grad = grad.view(B, L, Cc).permute(1, 0, 2).contiguous()
+        if dy_dx is None and grad.dtype == torch.float32 and inputs.dtype == torch.float32 and B >= 4096:
+            # large batches without an input gradient (the training step's sample encoding): the transposition to [L,B,C]
+            # merges runs of bitwise identical inputs on the way (csrc/grid_encode.hip grid_grad_runs_kernel)
+            grad = ops.grid_grad_runs(grad.contiguous(), inputs, B, D, L, Cc)
+        else:
+            grad = grad.view(B, L, Cc).permute(1, 0, 2).contiguous()
         grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         ops.grid_encode_backward(grad, inputs, embeddings.contiguous(), offsets, grad_embeddings, B, D,

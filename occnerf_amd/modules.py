@@ -93,7 +93,9 @@ class MotionBasisComputer(nn.Module):
         for joints, parents in self._levels(nb, dst_Rs.device):
             glob[:, joints] = torch.matmul(glob[:, parents], local[:, joints])
         dst = glob.view(-1, 4, 4)
-        f = torch.matmul(cnl_gtfms.view(-1, 4, 4), torch.inverse(dst)).view(B, nb, 4, 4)
+        # (linalg.inv_ex = torch.inverse without its host-side read of `info`: the same batched LU kernels, and capturable
+        # in the training step's hipGraph, occnerf_amd/train_graph.py; FK products of rigid transforms are never singular)
+        f = torch.matmul(cnl_gtfms.view(-1, 4, 4), torch.linalg.inv_ex(dst)[0]).view(B, nb, 4, 4)
         return f[:, :, :3, :3], f[:, :, :3, 3]
 
 
@@ -160,7 +162,14 @@ class _ConvT3dK4S2P1(torch.autograd.Function):
             rc = _lib.lib().occnerf_convt3d_im2col(gy.data_ptr(), Cout, D, H, W, dcols.data_ptr(), ops._stream(gy))
         _lib.check(rc, 'convt3d_im2col')
         dx = torch.mm(w2, dcols).reshape(Cin, D, H, W) if ctx.needs_input_grad[0] else None
-        dw = torch.mm(x2, dcols.t()).reshape(Cin, Cout, 4, 4, 4) if ctx.needs_input_grad[1] else None
+        if not ctx.needs_input_grad[1]:
+            dw = None
+        elif D * H * W == 1:
+            # the first layer (1024 -> 512 on a 1^3 grid: 33.5 M of the decoder's parameters) has a rank-1 weight gradient;
+            # as a K = 1 GEMM the library takes 0.34 ms for it, as a broadcast product the 134 MB are written in 0.03 ms
+            dw = (x2 * dcols.reshape(1, -1)).reshape(Cin, Cout, 4, 4, 4)
+        else:
+            dw = torch.mm(x2, dcols.t()).reshape(Cin, Cout, 4, 4, 4)
         db = gy.sum(dim=(1, 2, 3)) if has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 

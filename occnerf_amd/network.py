@@ -176,18 +176,24 @@ class Network(nn.Module):
         cm, nr = self.cnl_mlp.module, self.non_rigid_mlp.module
         nr_lin = [m for m in nr.block_mlps if isinstance(m, nn.Linear)]
         cw, cb = cm.linear_params()
-        bf16x3 = self.cfg.get('mlp_precision', 'fp32') == 'bf16x3'
+        prec = str(self.cfg.get('mlp_precision', 'fp32'))
+        if prec not in ('fp32', 'bf16x3', 'f16x3'):
+            raise RuntimeError(f"cfg.mlp_precision must be 'fp32', 'f16x3' or 'bf16x3', got {prec!r}")
+        # the split-operand kernels take their weights as a second, 2-byte stream: bf16 pieces (bf16x3) or fp16 pieces with a
+        # scaled low part (f16x3, fp32-grade: csrc/split.h); the ops dispatch on that stream's dtype
+        pack_c = {'bf16x3': ops.canonical_mlp_pack_bf16, 'f16x3': ops.canonical_mlp_pack_f16}.get(prec)
+        pack_n = {'bf16x3': ops.nonrigid_pack_bf16, 'f16x3': ops.nonrigid_pack_f16}.get(prec)
         srcs = cw + cb + [m.weight for m in nr_lin] + [m.bias for m in nr_lin]
-        key = (bf16x3,) + tuple((t.data_ptr(), t._version) for t in srcs)
+        key = (prec,) + tuple((t.data_ptr(), t._version) for t in srcs)
         if self._packed is not None and self._packed['key'] == key:
             return self._packed
         self._packed = {
             'key': key,
             'cnl': ops.canonical_mlp_pack(cw, cb),
-            'cnl_bf16': ops.canonical_mlp_pack_bf16(cw) if bf16x3 else None,
+            'cnl_bf16': pack_c(cw) if pack_c else None,
             'nr': ops.nonrigid_pack([m.weight.detach() for m in nr_lin],
                                     [m.bias.detach() for m in nr_lin]),
-            'nr_bf16': ops.nonrigid_pack_bf16([m.weight.detach() for m in nr_lin]) if bf16x3 else None,
+            'nr_bf16': pack_n([m.weight.detach() for m in nr_lin]) if pack_n else None,
             'nr_w0': nr_lin[0].weight.detach(), 'nr_b0': nr_lin[0].bias.detach(),
         }
         return self._packed
@@ -564,15 +570,19 @@ class Network(nn.Module):
                 with torch.autocast('cuda', enabled=False):
                     dst_Rs, dst_Ts, cnl_gtfms = dst_Rs.float(), dst_Ts.float(), cnl_gtfms.float()
                     dst_posevec = dst_posevec.float()
-                    if refine:                                                   # network.py:557-596
-                        refined = self.pose_decoder(dst_posevec)['Rs']
-                        tb = cfg.total_bones - 1
-                        no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3),
-                                               refined.reshape(-1, 3, 3)).reshape(-1, tb, 3, 3)
-                        dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
                     cond = dst_posevec if iter_val >= nr.kick_in_iter else torch.zeros_like(dst_posevec)
-                    Rs, Ts = self.motion_basis_computer(dst_Rs, dst_Ts, cnl_gtfms)
-                    vol = self.mweight_vol_decoder(motion_weights_priors=motion_weights_priors.float())[0]
+                    static = None
+                    if want_grad and cfg.get('train_graph', True):
+                        # pose refiner, Rodrigues, motion bases, volume decoder and the per-point SDF block
+                        # -- ~250 tiny launches forward, ~450 backward -- replayed as two hipGraphs (train_graph.py)
+                        from . import train_graph
+                        static = train_graph.get(self)(refine, dst_posevec, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors)
+                    if static is not None:
+                        Rs, Ts, vol, knn_base, point_sdf = static
+                    else:
+                        Rs, Ts = train_path.motion_bases(self, refine, dst_posevec, dst_Rs, dst_Ts, cnl_gtfms)
+                        vol = self.mweight_vol_decoder(motion_weights_priors=motion_weights_priors.float())[0]
+                        knn_base, point_sdf = train_path.point_sdf_block(self)      # once per step (the reference: every chunk)
                 rays8 = torch.cat([rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float(),
                                    near.reshape(-1, 1).float(), far.reshape(-1, 1).float()], -1)
                 order = morton_order(rays8[:, 3:6])
@@ -583,8 +593,8 @@ class Network(nn.Module):
                 outs = []
                 for i in range(0, rays8.shape[0], int(cfg.chunk)):
                     outs.append(train_path.render_rays_autograd(
-                        self, rays8[i:i + cfg.chunk], Rs[0], Ts[0], vol, bbox_min, bbox_scale, bgcolor, cond.float(),
-                        hann.tolist(), None if t_rand is None else t_rand[i:i + cfg.chunk]))
+                        self, rays8[i:i + cfg.chunk], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond.float(),
+                        hann.tolist(), None if t_rand is None else t_rand[i:i + cfg.chunk], point_block=(knn_base, point_sdf)))
                 rgb, acc, depth, comp_loss = (torch.cat(t, 0) if len(outs) > 1 else outs[0][j]
                                               for j, t in enumerate(zip(*outs)))
                 if order is not None:            # back to the caller's ray order

@@ -116,6 +116,16 @@ def _encoder_dtype(t, what):
     return t.dtype
 
 
+def grid_grad_runs(grad_rows, inputs, B, D, L, Cc):
+    """grad_rows[B, L*C] fp32 -> [L,B,C] with the rows of runs of bitwise identical inputs summed into the run's first sample."""
+    out = torch.empty(L, B, Cc, device=grad_rows.device, dtype=torch.float32)
+    with _guard(grad_rows):
+        rc = _lib.lib().occnerf_grid_grad_runs(_chk(grad_rows, torch.float32, 'grad_rows'), _chk(inputs, torch.float32, 'inputs'),
+                                               int(B), int(D), int(L), int(Cc), out.data_ptr(), _stream(grad_rows))
+    _lib.check(rc, 'grid_grad_runs')
+    return out
+
+
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H, dy_dx=None,
                         gridtype=0, align_corners=False, interp=0):
     """Same positional signature as the reference's `_gridencoder.grid_encode_forward`
@@ -388,8 +398,35 @@ def nonrigid_pack_bf16(weights):
     return packed
 
 
+def nonrigid_pack_f16(weights):
+    """Split-fp16 operand stream of the non-rigid MLP (cfg.mlp_precision = 'f16x3': csrc/split.h F16x3)."""
+    dev = weights[0].device
+    n = _lib.lib().occnerf_nonrigid_packed_bf16_bytes()               # same layout, 2-byte elements
+    packed = torch.zeros(n // 2, device=dev, dtype=torch.float16)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_nonrigid_pack_f16(_ptr_table(weights[:6], 'W'), packed.data_ptr(), _stream(packed))
+    _lib.check(rc, 'nonrigid_pack_f16')
+    return packed
+
+
+def _nonrigid_f16x3(xyz, rows, count, cond, hann, W0, b0, packed, packed_f16, out):
+    _kh, ph = _host_f32(hann, 6)
+    n_max = xyz.shape[0] if rows is None else rows.shape[0]
+    with _guard(xyz):
+        rc = _lib.lib().occnerf_nonrigid_f16x3(
+            _chk(xyz, torch.float32, 'xyz'), n_max, _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'),
+            _chk(cond, torch.float32, 'cond'), ph, _chk(W0, torch.float32, 'W0'), _chk(b0, torch.float32, 'b0'),
+            _chk(packed, torch.float32, 'packed'), _chk(packed_f16, torch.float16, 'packed_f16'),
+            _chk(out, torch.float32, 'xyz_out'), _stream(xyz))
+    _lib.check(rc, 'nonrigid_f16x3')
+    return out
+
+
 def nonrigid_bf16x3(xyz, cond, hann, W0, b0, packed, packed_bf16, out=None):
+    """Split-operand non-rigid MLP; the dtype of the packed stream selects the split (bfloat16: bf16x3, float16: f16x3)."""
     out = torch.empty_like(xyz) if out is None else out
+    if packed_bf16.dtype == torch.float16:
+        return _nonrigid_f16x3(xyz, None, None, cond, hann, W0, b0, packed, packed_bf16, out)
     _kh, ph = _host_f32(hann, 6)
     with _guard(xyz):
         rc = _lib.lib().occnerf_nonrigid_bf16x3(
@@ -401,7 +438,9 @@ def nonrigid_bf16x3(xyz, cond, hann, W0, b0, packed, packed_bf16, out=None):
 
 
 def nonrigid_bf16x3_rows(xyz, rows, count, cond, hann, W0, b0, packed, packed_bf16):
-    """In place on the listed samples (the split-bf16 counterpart of nonrigid_rows): xyz[rows[i]] += offset, i < count[0]."""
+    """In place on the listed samples (the split-operand counterpart of nonrigid_rows): xyz[rows[i]] += offset, i < count[0]."""
+    if packed_bf16.dtype == torch.float16:
+        return _nonrigid_f16x3(xyz, rows, count, cond, hann, W0, b0, packed, packed_bf16, xyz)
     _kh, ph = _host_f32(hann, 6)
     with _guard(xyz):
         rc = _lib.lib().occnerf_nonrigid_bf16x3_rows(
@@ -637,9 +676,31 @@ def canonical_mlp_pack_bf16(weights):
     return packed
 
 
+def canonical_mlp_pack_f16(weights):
+    """Split-fp16 operand stream of the canonical MLP (cfg.mlp_precision = 'f16x3': csrc/split.h F16x3): Wh = f16(W),
+    Wl' = f16((W - Wh) 2^11), in fp16-MFMA operand order."""
+    dev = weights[0].device
+    n = _lib.lib().occnerf_canonical_mlp_packed_bf16_bytes()          # same layout, 2-byte elements
+    packed = torch.zeros(n // 2, device=dev, dtype=torch.float16)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_canonical_mlp_pack_f16(_ptr_table(weights, 'W'), packed.data_ptr(), _stream(packed))
+    _lib.check(rc, 'canonical_mlp_pack_f16')
+    return packed
+
+
 def canonical_mlp_bf16x3(mlp_in, packed, packed_bf16, raw, variant=0, count=None, in_rows=None):
-    """count (int32[1] on the device): entries to evaluate, read by the kernel (the launch covers the worst case);
+    """Split-operand canonical MLP; the dtype of the packed stream selects the split (bfloat16: bf16x3, float16: f16x3).
+    count (int32[1] on the device): entries to evaluate, read by the kernel (the launch covers the worst case);
     in_rows (int32, optional): entry n takes input row in_rows[n]; results are compact (raw[n])."""
+    if packed_bf16.dtype == torch.float16:
+        n_max = mlp_in.shape[0] if in_rows is None else in_rows.shape[0]
+        with _guard(mlp_in):
+            rc = _lib.lib().occnerf_canonical_mlp_f16x3(
+                _chk(mlp_in, torch.float32, 'mlp_in'), _opt(in_rows, torch.int32, 'in_rows'), n_max,
+                _opt(count, torch.int32, 'count'), _chk(packed, torch.float32, 'packed'),
+                _chk(packed_bf16, torch.float16, 'packed_f16'), _chk(raw, torch.float32, 'raw'), _stream(mlp_in))
+        _lib.check(rc, 'canonical_mlp_f16x3')
+        return raw
     with _guard(mlp_in):
         if count is None:
             assert in_rows is None
@@ -716,6 +777,26 @@ def prior_softmax(decoded, prior):
     return vol
 
 
+def ray_order(dirs):
+    """dirs: [R,3] float32 GPU tensor (any row stride, unit element stride: a slice of rays8 works) -> int64[R], the Morton
+    walk of the rays (csrc/rays.hip; occnerf_amd/rayorder.py is the same construction in torch ops).  No sync."""
+    R = dirs.shape[0]
+    order = torch.empty(R, device=dirs.device, dtype=torch.int64)
+    if R == 0:
+        return order
+    if not dirs.is_cuda or dirs.dtype != torch.float32 or dirs.dim() != 2 or dirs.shape[1] != 3 or dirs.stride(1) != 1:
+        raise RuntimeError('ray_order: dirs must be a float32 [R,3] GPU tensor with unit element stride')
+    nbytes = int(_lib.lib().occnerf_ray_order_temp_bytes(R))
+    if nbytes < 0:
+        raise RuntimeError('ray_order: temp size query failed')
+    temp = torch.empty(nbytes, device=dirs.device, dtype=torch.uint8)
+    with _guard(dirs):
+        rc = _lib.lib().occnerf_ray_order(dirs.data_ptr(), R, int(dirs.stride(0)), order.data_ptr(), temp.data_ptr(), nbytes,
+                                          _stream(dirs))
+    _lib.check(rc, 'ray_order')
+    return order
+
+
 def pack_rays(rays, near, far, order=None):
     """rays[2,R,3], near[R,1], far[R,1] -> rays8[R,8] in `order` (int64 permutation, optional)."""
     R = rays.shape[1]
@@ -746,10 +827,13 @@ def agg_backward(grad_agg, knn, atts, P):
     F = grad_agg.shape[1]
     W = int(_lib.lib().occnerf_agg_backward_slices(N))
     partial = torch.empty(W, P, F, device=grad_agg.device, dtype=torch.float32)
+    nbytes = int(_lib.lib().occnerf_agg_backward_scratch_bytes(N, int(F)))
+    scratch = torch.empty(max(nbytes, 16), device=grad_agg.device, dtype=torch.uint8)
     with _guard(grad_agg):
         rc = _lib.lib().occnerf_agg_backward(_chk(grad_agg, torch.float32, 'grad_agg'), int(F),
                                              _chk(knn, torch.int32, 'knn'), _chk(atts, torch.float32, 'atts'), N,
-                                             int(K), int(P), partial.data_ptr(), _stream(grad_agg))
+                                             int(K), int(P), partial.data_ptr(), scratch.data_ptr(), nbytes,
+                                             _stream(grad_agg))
     _lib.check(rc, 'agg_backward')
     return partial.sum(0)
 

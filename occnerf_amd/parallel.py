@@ -115,13 +115,18 @@ class ShardedRenderer:
     """Renders frames with their rays sharded over the ranks of `group` (see the module docstring)."""
 
     def __init__(self, net, device, group=None, block=BLOCK, channels=5, single=False, morton=True, chunk=None,
-                 balance=True, force_collective=None, verify_plan=True):
+                 balance=True, force_collective=None, verify_plan=True, emulate=None):
         """single: ignore the process group, this process renders whole frames by itself.  morton=False deals the
         caller's own ray order.  balance=False: static dealing (block b -> rank b % N) even when the network can
         estimate block costs.  chunk: older name of `block`.  force_collective (default: env OCC_FORCE_COLLECTIVE=1): a
         process group of ONE rank still takes the N > 1 branch -- Morton-block plan, padded send buffer, asynchronous
         `dist.gather` into the list-of-views receive buffer, `work.wait()`, un-permutation -- so that the RCCL path runs on
-        a single-GPU box exactly as it does on a node.  verify_plan=False skips the plan checksum exchange."""
+        a single-GPU box exactly as it does on a node.  verify_plan=False skips the plan checksum exchange.
+        emulate=(N, k): act as rank k of a world of N inside THIS process (bench.py's `predicted_scaling`, while no multi-GPU
+        node is available): the plan is the N-rank plan, this rank's share is gathered from the host frame / rendered / copied
+        to the padded send buffer exactly as rank k would, and the frame's gather is issued on a ONE-rank process group into
+        rank k's slot of the N-slot receive buffer (RCCL self-gather; a plain device copy when no group is initialised);
+        rank 0 un-permutes the buffer (the other slots hold no pixels: timing only), ranks k > 0 return None like real ones."""
         self.net, self.device, self.group, self.channels = net, torch.device(device), group, channels
         self.block = int(chunk if chunk is not None else block)
         self.morton = bool(morton)
@@ -134,6 +139,12 @@ class ShardedRenderer:
         # collective: this renderer exchanges blocks through the process group (always when it has more than one rank)
         self.collective = bool(formed and (self.world > 1 or force_collective))
         self.verify_plan = bool(verify_plan)
+        self.emulate = None
+        if emulate is not None:
+            n, k = int(emulate[0]), int(emulate[1])
+            if not (n >= 1 and 0 <= k < n) or (formed and dist.get_world_size(group) != 1):
+                raise RuntimeError(f'ShardedRenderer(emulate={emulate!r}): needs 0 <= k < N and at most a one-rank process group')
+            self.emulate, self.world, self.rank, self.collective, self.verify_plan = (n, k), n, k, True, False
         self.backend = dist.get_backend(group) if formed else None
         # gloo has no gather on device tensors: with that backend (tests: several processes sharing one GPU) the blocks
         # are exchanged through host buffers; with nccl (= RCCL) they stay on the device
@@ -366,6 +377,18 @@ class ShardedRenderer:
         # check's event was recorded ahead of the frame's kernels, so this waits for the checksum exchange only (once per
         # new plan; later frames of the plan find nothing pending).
         self._verify_plan(plan)
+        if self.emulate is not None:
+            # rank k's block into rank k's slot of the N-slot receive buffer, through the one-rank group when there is one
+            if bufs.get('recv') is None:
+                bufs['recv'] = [torch.zeros(self.world * plan['width'], self.channels, device=self.device) for _ in range(2)]
+            mine = bufs['recv'][slot].view(self.world, plan['width'], self.channels)[self.rank]
+            if self.backend is not None:
+                work = dist.gather(send, [mine], dst=0, group=self.group, async_op=True)
+                self.gathers_issued += 1
+            else:
+                mine.copy_(send)
+                work = None
+            return _Pending(work, slot, R, plan, bufs)
         if self.host_exchange:
             send = bufs['send_host'][slot].copy_(send)               # (synchronous: the gloo path is a test vehicle)
             rbuf = bufs['recv_host'][slot] if self.rank == 0 else None
@@ -383,7 +406,8 @@ class ShardedRenderer:
         if not self.collective:
             full = bufs['send'][pending.slot][:pending.n_rays].clone()
         else:
-            pending.work.wait()
+            if pending.work is not None:
+                pending.work.wait()
             self._verify_plan(plan)
             if self.rank != 0:
                 return None

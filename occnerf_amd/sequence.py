@@ -25,16 +25,18 @@ class SyntheticFrames:
     moving along (create_dataset.py:40-42 `maxframes = 300` under evaluate)."""
 
     def __init__(self, data_type, img_size=512, render_frames=100, bgcolor=(255., 255., 255.), device_rays=True,
-                 freeview_frame_idx=0):
+                 freeview_frame_idx=0, frame_range=None):
         self.data_type, self.img_size = data_type, int(img_size)
         self.bgcolor, self.device_rays, self.freeview_frame_idx = bgcolor, bool(device_rays), int(freeview_frame_idx)
         self.avg_betas = np.zeros(10, dtype='float32')
         self.total_frames = {'tpose': 1, 'allview': 23, 'progress': min(300, int(render_frames))}.get(
             data_type, int(render_frames))
         self.dataset = self                     # run.py reads test_loader.dataset.avg_betas
+        # frame_range=(first, count): iterate over a window of the sequence only (bench.py: 8 consecutive orbit frames)
+        self.frame_range = None if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
 
     def __len__(self):
-        return self.total_frames
+        return self.total_frames if self.frame_range is None else self.frame_range[1]
 
     def pose(self, idx):
         if self.data_type == 'tpose':
@@ -51,7 +53,8 @@ class SyntheticFrames:
             orbit_period=max(self.total_frames, 1), bgcolor=self.bgcolor, with_rays=not self.device_rays)
 
     def __iter__(self):
-        for idx in range(self.total_frames):
+        lo, n = (0, self.total_frames) if self.frame_range is None else self.frame_range
+        for idx in range(lo, lo + n):
             batch = {}
             for k, v in self.frame(idx).items():
                 batch[k] = torch.as_tensor(np.asarray(v))[None] if not np.isscalar(v) else v

@@ -442,7 +442,7 @@ _PRIOR_CACHE = {}
 
 def make_frame(img_size=512, pose72=None, orbit_frame=0, orbit_period=100,
                bgcolor=(255.0, 255.0, 255.0), betas=None, bbox_offset=0.3, volume_size=32,
-               rotate_axis='y', with_rays=True):
+               rotate_axis='y', with_rays=True, camera_radius=6.0, camera_focal=1250.0):
     """One frame of renderer inputs, T-pose (pose72 None/zeros, tpose.py:133-217) or a
     posed free-view orbit frame (freeview.py:177-269).  with_rays=False leaves the ray batch to the device
     (occnerf_amd/rays.py) and returns the camera and the observation-space bbox instead."""
@@ -453,7 +453,7 @@ def make_frame(img_size=512, pose72=None, orbit_frame=0, orbit_period=100,
     dst_joints = posed_joints(pose, cjoints) if np.any(pose != 0) else cjoints
     dst_bbox = skeleton_to_bbox(dst_joints, bbox_offset)
 
-    K, E = setup_camera(img_size)
+    K, E = setup_camera(img_size, radius=camera_radius, focal=camera_focal)
     if orbit_frame:
         angle = 2 * np.pi * (orbit_frame / orbit_period)
         E = rotate_camera(E, angle, rotate_axis=rotate_axis).astype('float32')

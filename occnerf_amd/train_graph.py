@@ -39,15 +39,10 @@ class _StaticPart(nn.Module):
 
     def forward(self, posevec, dst_Rs, dst_Ts, cnl_gtfms, prior):
         from . import train_path
-        if self.refine:                                                   # network.py:557-596
-            refined = self.pose_decoder(posevec)['Rs']
-            tb = self.total_bones - 1
-            no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3), refined.reshape(-1, 3, 3)).reshape(-1, tb, 3, 3)
-            dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
-        Rs, Ts = self.motion_basis_computer(dst_Rs, dst_Ts, cnl_gtfms)
+        Rs, Ts = train_path.motion_bases(self.net, self.refine, posevec, dst_Rs, dst_Ts, cnl_gtfms)
         vol = self.mweight_vol_decoder(motion_weights_priors=prior)[0]
         knn_base, sdf = train_path.point_sdf_block(self.net)
-        return Rs[0], Ts[0], vol, knn_base, sdf
+        return Rs, Ts, vol, knn_base, sdf
 
 
 class PerStepGraph:

@@ -313,3 +313,50 @@ def agg_weights(counter, knn):
                                             N, K, atts.data_ptr(), var.data_ptr(), ops._stream(knn))
     _lib.check(rc, 'agg_weights')
     return atts, var
+
+
+# ------------------------------------------------------------------ pose refiner -> motion bases
+class _PoseMotionBases(Function):
+    """(posevec[69], dst_Rs[24,3,3], dst_Ts[24,3], cnl_gtfms[24,4,4], W0..W4, b0..b4) -> Rs[24,3,3], Ts[24,3] with
+    refinement on: the fused forward of the renderer (csrc/preamble.hip pose_motion_bases_kernel) and a fused backward
+    to the ten parameters (pose_motion_bases_backward_kernel) -- two launches where torch autograd takes ~560."""
+
+    @staticmethod
+    def forward(ctx, posevec, dst_Rs, dst_Ts, cnl_gtfms, *wb):
+        W, b = [t.detach().float().contiguous() for t in wb[:5]], [t.detach().float().contiguous() for t in wb[5:]]
+        dev = dst_Rs.device
+        args = [t.detach().float().contiguous() for t in (posevec.reshape(-1), dst_Rs, dst_Ts, cnl_gtfms)]
+        Rs = torch.empty(24, 3, 3, device=dev, dtype=torch.float32)
+        Ts = torch.empty(24, 3, device=dev, dtype=torch.float32)
+        with ops._guard_dev(dev):
+            rc = _lib.lib().occnerf_pose_motion_bases(ops._ptr_table(W, 'W'), ops._ptr_table(b, 'b'), args[0].data_ptr(), 1,
+                                                      args[1].data_ptr(), args[2].data_ptr(), args[3].data_ptr(), Rs.data_ptr(),
+                                                      Ts.data_ptr(), ops._stream(dst_Rs))
+        _lib.check(rc, 'pose_motion_bases')
+        ctx.save_for_backward(*args, *W, *b)
+        return Rs, Ts
+
+    @staticmethod
+    def backward(ctx, dRs, dTs):
+        saved = ctx.saved_tensors
+        args, W, b = saved[:4], list(saved[4:9]), list(saved[9:14])
+        dev = args[1].device
+        dRs = (torch.zeros(24, 3, 3, device=dev) if dRs is None else dRs).float().contiguous()
+        dTs = (torch.zeros(24, 3, device=dev) if dTs is None else dTs).float().contiguous()
+        dW, db = [torch.empty_like(w) for w in W], [torch.empty_like(x) for x in b]
+        with ops._guard_dev(dev):
+            rc = _lib.lib().occnerf_pose_motion_bases_backward(
+                ops._ptr_table(W, 'W'), ops._ptr_table(b, 'b'), args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(),
+                args[3].data_ptr(), dRs.data_ptr(), dTs.data_ptr(), ops._ptr_table(dW, 'dW'), ops._ptr_table(db, 'db'),
+                ops._stream(dRs))
+        _lib.check(rc, 'pose_motion_bases_backward')
+        return (None, None, None, None) + tuple(dW) + tuple(db)
+
+
+def pose_motion_bases(pose_decoder, posevec, dst_Rs, dst_Ts, cnl_gtfms):
+    """Refined motion bases with gradients to the pose refiner's parameters.  pose_decoder: BodyPoseRefiner (69 -> 256 x4 -> 69)."""
+    import torch.nn as nn
+    lin = [m for m in pose_decoder.block_mlps if isinstance(m, nn.Linear)]
+    if len(lin) != 5 or lin[0].in_features != 69 or lin[0].out_features != 256 or lin[4].out_features != 69:
+        raise RuntimeError('pose_motion_bases: the fused kernels are built for the 69 -> 256 x4 -> 69 refiner of occnerf.yaml')
+    return _PoseMotionBases.apply(posevec, dst_Rs, dst_Ts, cnl_gtfms, *[m.weight for m in lin], *[m.bias for m in lin])

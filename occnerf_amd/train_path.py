@@ -57,6 +57,26 @@ def warp_to_canonical(pts, Rs, Ts, vol, bbox_min, bbox_scale):
     return x_skel.reshape(shape), wsum.reshape(shape[0], shape[1], 1)
 
 
+def motion_bases(net, refine, posevec, dst_Rs, dst_Ts, cnl_gtfms):
+    """network.py:557-596 + network_util.py:166-200 with gradients to the pose refiner: (posevec[1,69], dst_Rs[1,24,3,3],
+    dst_Ts[1,24,3], cnl_gtfms[1,24,4,4]) -> Rs[24,3,3], Ts[24,3].  Default: the renderer's fused forward kernel and a fused
+    backward (train_ops.pose_motion_bases: 2 launches); cfg.train_fused_pose=False: the torch modules under autograd (~560
+    launches), kept as the reference the fused pair is tested against."""
+    if net.cfg.get('train_fused_pose', True) and posevec.is_cuda:
+        if refine:
+            return train_ops.pose_motion_bases(net.pose_decoder, posevec[0], dst_Rs[0], dst_Ts[0], cnl_gtfms[0])
+        with torch.no_grad():          # before the kick-in iteration the bases are constants of the frame
+            return ops.pose_motion_bases(net.pose_decoder, posevec[0].float().contiguous(), False, dst_Rs[0].float().contiguous(),
+                                         dst_Ts[0].float().contiguous(), cnl_gtfms[0].float().contiguous())
+    if refine:
+        refined = net.pose_decoder(posevec)['Rs']
+        tb = int(net.cfg.total_bones) - 1
+        no_root = torch.matmul(dst_Rs[:, 1:].reshape(-1, 3, 3), refined.reshape(-1, 3, 3)).reshape(-1, tb, 3, 3)
+        dst_Rs = torch.cat([dst_Rs[:, 0:1], no_root], dim=1)
+    Rs, Ts = net.motion_basis_computer(dst_Rs, dst_Ts, cnl_gtfms)
+    return Rs[0], Ts[0]
+
+
 def point_sdf_block(net):
     """network.py:263-284 with gradients to point_dist -> knn_base[P,3] (f64), dist[P,1]."""
     pc = net.point_cloud.float()
@@ -64,7 +84,9 @@ def point_sdf_block(net):
     kidx = ops.knn_small(pc.detach().contiguous(), base, 3).long()
     nbr = base[kidx]                                                             # [P,3,3]
     direction = pc[:, None, :] - nbr
-    norms = net.point_norms.to(pc.device)[kidx]                                  # float64
+    # (the device copy of the float64 normals kept by Network._context: `net.point_norms` is a plain host attribute as in the
+    # reference, network.py:122, and moving it every step is a synchronous 165 KB copy -- and not capturable in a hipGraph)
+    norms = net._context()['normals'][kidx]                                      # float64
     att = torch.abs(F.cosine_similarity(direction, norms, dim=-1))[..., None]
     knn_base = (att * nbr).sum(1) / att.sum(1)
     # (row-wise dot products; the reference's einsum 'ijk,ijk->ij' runs as 20 670 batched 1x3x1 GEMMs: 0.28 ms)
@@ -80,7 +102,7 @@ def canonical_mlp_torch(cm, xyz, knn_idxs, net, knn_base, point_sdf):
     base = net.point_base.detach()
     idx0 = knn_idxs[:, 0].long()
     knn_points = base[idx0]                                                      # [N,10,3]
-    normals = net.point_norms.to(xyz.device)[idx0]                               # float64
+    normals = net._context()['normals'][idx0]                                    # float64
     with torch.no_grad():
         direction = xyz[:, None, :] - knn_points
         # row-wise fp64 dot products (the reference's einsum 'ijk,ijk->ij' runs as a batched fp64 GEMM: 13 ms
@@ -182,16 +204,24 @@ def _bump_counter(net, kidx):
 
 
 def _training_branch(net, raw, depth, term, cnl_pts):
-    """network.py:486-517: comp_loss per sample and the visibility-counter update (training mode only)."""
+    """network.py:486-517: comp_loss per sample and the visibility-counter update (training mode only).
+    The reference selects the rays with depth > 0.5 on the host (`if depth_mask.sum() > 1`, boolean indexing): a device ->
+    host round trip in the middle of the step.  Here the search runs for every ray's arg-max-alpha sample (6 144 queries:
+    0.3 ms) and the selection is a weight in a device-side scatter -- the same points are incremented (duplicates count once,
+    as with the reference's non-accumulating index_put), and the step has no synchronisation point."""
     dist, sigma = raw[..., 4:], raw[..., 3:4]        # (a slice: the reference's list index [3] backpropagates as an index_put)
     comp_loss = (dist < 0.).float().detach() * torch.exp(torch.clamp(-F.relu(sigma), min=-10, max=0))
     comp_loss = comp_loss.squeeze(-1) * 10.
-    depth_mask = depth.detach() > 0.5
-    if int(depth_mask.sum()) > 1:
-        tp = term[depth_mask].detach().long()
-        term_pts = torch.gather(cnl_pts[depth_mask].detach(), 1, tp[:, :, None].expand(-1, 1, 3)).squeeze(1)
+    with torch.no_grad():
+        depth_mask = depth.detach() > 0.5
+        tp = term.detach().long()
+        term_pts = torch.gather(cnl_pts.detach(), 1, tp[:, :, None].expand(-1, 1, 3)).squeeze(1)      # [n,3], every ray
         kidx = ops.knn_small(term_pts.float().contiguous(), net.point_cloud.detach().float().contiguous(), 10)
-        _bump_counter(net, kidx)
+        w = (depth_mask & (depth_mask.sum() > 1)).to(torch.float32)
+        hit = torch.zeros_like(net.point_counter.data, dtype=torch.float32)
+        hit.index_add_(0, kidx.view(-1).long(), w[:, None].expand(-1, kidx.shape[1]).reshape(-1))
+        net.point_counter.data += (hit > 0).to(net.point_counter.dtype)
+        torch.autograd.graph.increment_version(net.point_counter)       # (see _bump_counter)
     return comp_loss
 
 
@@ -235,9 +265,10 @@ def canonical_mlp_hip(cm, xyz, knn_idxs, net, knn_base, point_sdf, ctx, bf16):
     return torch.cat((raw4, dist), dim=-1)
 
 
-def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, t_rand=None):
+def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, t_rand=None, point_block=None):
     """Differentiable counterpart of Network._render_rays (+ the training branch a18).
-    bbox_min, bbox_scale, bgcolor: HOST float32[3]; hann: HOST list of the 6 window weights."""
+    bbox_min, bbox_scale, bgcolor: HOST float32[3]; hann: HOST list of the 6 window weights; point_block: the step's
+    (knn_base, sdf) of point_sdf_block when the caller has evaluated it already (once per step, inside the hipGraph)."""
     cfg, ctx = net.cfg, net._context()
     bf16 = _use_bf16(cfg)                 # (asked before autocast is switched off for the fp32 stages below)
     S = int(cfg.N_samples)
@@ -259,7 +290,7 @@ def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor,
     with torch.no_grad():
         knn = ops.msknn_clustered(xyz, n, S, ctx['clusters'], ctx['seed'])
     with torch.autocast('cuda', enabled=False):
-        knn_base, sdf = point_sdf_block(net)
+        knn_base, sdf = point_sdf_block(net) if point_block is None else point_block
         raw = canonical_mlp_hip(net.cnl_mlp.module, xyz, knn, net, knn_base, sdf, ctx, bf16)
         rgb, acc, depth, term = train_ops.composite(raw, mask, z, rays8, bgcolor)
         if net.training:

@@ -27,7 +27,7 @@ def test_python_binding_covers_the_header():
     from occnerf_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.lib()
-    assert lib.occnerf_abi_version() == 3
+    assert lib.occnerf_abi_version() == 4
     assert lib.occnerf_canonical_mlp_packed_floats() == 479812 + 0 or lib.occnerf_canonical_mlp_packed_floats() > 461568
 
 

@@ -74,7 +74,7 @@ def _dev_model(ctx, ops):
 
 def test_library_is_the_hip_build(ops):
     from occnerf_amd import _lib
-    assert _lib.lib().occnerf_abi_version() == 3
+    assert _lib.lib().occnerf_abi_version() == 4
     assert torch.cuda.is_available() and 'gfx950' in torch.cuda.get_device_properties(0).gcnArchName
 
 
@@ -663,6 +663,56 @@ def test_canonical_mlp_bf16x3(case, ops):
     same(outs[0], outs[1], 'bf16x3 LDS vs direct')   # same products, same order
 
 
+def test_canonical_mlp_f16x3(case, ops):
+    """The fp32-grade split (cfg.mlp_precision = 'f16x3', csrc/split.h): two fp16 pieces per operand kept in the normal range,
+    three MFMA products, fp32 accumulation -- held to the fp32 kernel's OWN tolerances: the tolerances of
+    test_sample_features_and_mlp's "MLP alone on identical inputs against float64" for the three checkpoints
+    (1e-6 random-init, 5e-5 amplified, 5e-4 trained-like), with the fp32 kernel's error printed beside it."""
+    g, ctx, o = case
+    Wg, Bg, Wc, Bc = util.canonical_mlp_params(ctx['sd'])
+    W = [T(w) for w in Wg + Wc]
+    B = [T(b) for b in Bg + Bc]
+    packed, packed_h = ops.canonical_mlp_pack(W, B), ops.canonical_mlp_pack_f16(W)
+    assert packed_h.dtype == torch.float16
+    from tests.test_oracle_golden import _mlp_f64
+    ref = _mlp_f64(o['mlp_in'], Wg, Bg, Wc, Bc)
+    raw = torch.zeros(o['mlp_in'].shape[0], 5, device=DEV)
+    ops.canonical_mlp_bf16x3(T(o['mlp_in']), packed, packed_h, raw)
+    raw32 = torch.zeros_like(raw)
+    ops.canonical_mlp(T(o['mlp_in']), packed, raw32)
+    err, err32 = np.abs(raw.cpu().numpy()[:, :4] - ref).max(), np.abs(raw32.cpu().numpy()[:, :4] - ref).max()
+    print(f'\n   f16x3 vs float64 {err:.3e}   (fp32 kernel {err32:.3e}; |outputs| up to {np.abs(ref).max():.3g})')
+    assert err <= util.pick(g, 1e-6, 5e-5, 5e-4), err
+
+
+@pytest.mark.parametrize('n', [1, 31, 32, 33, 127, 128, 129, 1000, 4097])
+def test_canonical_mlp_f16x3_ragged(ops, n):
+    """As test_canonical_mlp_ragged (the fp32 kernel's test, same inputs, same 1e-6 against float64): workgroups of 4 waves x
+    32 samples, partial waves and workgroups, column 4 and the guard rows untouched; and through a row list with the count on
+    the device.  Inputs of amplitude 1e-4 (what a random-init hash table produces) and 30 (beyond any trained activation
+    seen) exercise the subnormal-piece and the large-value ends of the fp16 range."""
+    ctx = util.model_context(0, False)
+    Wg, Bg, Wc, Bc = util.canonical_mlp_params(ctx['sd'])
+    W = [T(w) for w in Wg + Wc]
+    packed, packed_h = ops.canonical_mlp_pack(W, [T(b) for b in Bg + Bc]), ops.canonical_mlp_pack_f16(W)
+    from tests.test_oracle_golden import _mlp_f64
+    rng = np.random.default_rng(n)
+    for amp, tol in ((0.3, 1e-6), (1e-4, 1e-6), (30.0, 1e-4)):        # (amp 30: outputs ~1e2, the fp32 kernel's error there is 3e-5)
+        x = (rng.standard_normal((n, 68)) * amp).astype(np.float32)
+        raw = torch.full((n + 3, 5), 7.0, device=DEV)             # 3 guard rows behind the batch
+        ops.canonical_mlp_bf16x3(T(x), packed, packed_h, raw[:n])
+        got = raw.cpu().numpy()
+        want = _mlp_f64(x, Wg, Bg, Wc, Bc)
+        assert np.abs(got[:n, :4] - want).max() <= tol * max(1.0, np.abs(want).max() if amp > 1 else 1.0), (amp, np.abs(got[:n, :4] - want).max())
+        assert (got[:n, 4] == 7.0).all() and (got[n:] == 7.0).all()
+    if n >= 127:
+        rows = torch.randperm(n, device=DEV).int()
+        count = torch.tensor([n - 5], device=DEV, dtype=torch.int32)
+        a = ops.canonical_mlp_bf16x3(T(x), packed, packed_h, torch.zeros(n, 5, device=DEV), count=count, in_rows=rows)
+        b = ops.canonical_mlp_bf16x3(T(x)[rows.long()][:n - 5].contiguous(), packed, packed_h, torch.zeros(n - 5, 5, device=DEV))
+        assert torch.equal(a[:n - 5], b) and float(a[n - 5:].abs().max()) == 0.0
+
+
 def test_canonical_mlp_module_gathered_interface(case, ops):
     """CanonicalMLP.forward with the reference's keyword surface (gathered neighbours)."""
     g, ctx, o = case
@@ -749,9 +799,24 @@ def test_nonrigid(case, ops):
     ph = ops.nonrigid_pack_bf16(Wd)
     gotb = ops.nonrigid_bf16x3(T(xyz), T(cond), np.ones(6, np.float32), Wd[0], Bd[0], packed, ph).cpu().numpy()
     assert np.abs(gotb - orc.nonrigid(xyz, cond, np.ones(6, np.float32), W, B)).max() <= 5e-6
+    # the fp32-grade split (f16x3): the fp32 kernel's own 1e-6, both window settings, in place on a row list too
+    pf = ops.nonrigid_pack_f16(Wd)
+    for hann in (np.ones(6, np.float32), np.array([1, 1, 0.75, 0.25, 0, 0], np.float32)):
+        gotf = ops.nonrigid_bf16x3(T(xyz), T(cond), hann, Wd[0], Bd[0], packed, pf).cpu().numpy()
+        assert np.abs(gotf - orc.nonrigid(xyz, cond, hann, W, B)).max() <= 1e-6
+    lrows = torch.arange(0, xyz.shape[0], 3, device=DEV, dtype=torch.int32)
+    lcount = torch.tensor([lrows.numel() - 2], device=DEV, dtype=torch.int32)
+    inpl = ops.nonrigid_bf16x3_rows(T(xyz).clone(), lrows, lcount, T(cond), np.ones(6, np.float32), Wd[0], Bd[0], packed, pf).cpu().numpy()
+    sel = lrows.cpu().numpy()[:lrows.numel() - 2]
+    keep = np.ones(xyz.shape[0], bool)
+    keep[sel] = False
+    assert np.abs(inpl[sel] - orc.nonrigid(xyz[sel], cond, np.ones(6, np.float32), W, B)).max() <= 1e-6
+    assert np.array_equal(inpl[keep], xyz[keep])
     if 'nr.xyz_out' in g:                                # what the reference's torch MLP returned
         got = ops.nonrigid(T(xyz), T(cond), np.ones(6, np.float32), Wd[0], Bd[0], packed).cpu().numpy()
         assert np.abs(got - g['nr.xyz_out']).max() <= 1e-6
+        gotf = ops.nonrigid_bf16x3(T(xyz), T(cond), np.ones(6, np.float32), Wd[0], Bd[0], packed, pf).cpu().numpy()
+        assert np.abs(gotf - g['nr.xyz_out']).max() <= 1e-6
 
 
 # ----------------------------------------------------------------------------- a17
@@ -928,6 +993,48 @@ def test_network_end_to_end_bf16x3(case):
         assert np.abs(out[k].cpu().numpy() - g['out.' + k]).max() <= tol, k
 
 
+def test_network_end_to_end_f16x3(case):
+    """cfg.mlp_precision = 'f16x3' (the fp32-grade split of round 5) against the reference's own output: the fp32 path's gate on
+    ALL THREE checkpoints -- 1e-4 random-init, 1e-3 amplified, 1e-4 trained-like (where bf16x3 fails it) -- and the kNN indices
+    downstream of the split non-rigid offsets unchanged on the fixture (pixels would move by 1e-3 where a neighbour set flips)."""
+    g, ctx, o = case
+    nr = bool(int(g['meta.non_rigid']))
+    net, _ = build_network(int(g['meta.seed']), util.level(g), S=int(g['meta.S']), non_rigid=nr, mlp_precision='f16x3')
+    net32, _ = build_network(int(g['meta.seed']), util.level(g), S=int(g['meta.S']), non_rigid=nr)
+    with torch.no_grad():
+        out = net(**frame_to_device(g, DEV), iter_val=1e7)
+        out32 = net32(**frame_to_device(g, DEV), iter_val=1e7)
+    print()
+    for k in ('rgb', 'alpha', 'depth'):
+        e, e32 = np.abs(out[k].cpu().numpy() - g['out.' + k]).max(), np.abs(out32[k].cpu().numpy() - g['out.' + k]).max()
+        print(f'   {k:5s}: max |f16x3 - reference| {e:.3e}   (fp32 path {e32:.3e}; gate {util.pixel_tol(g):g})')
+        assert e <= util.pixel_tol(g), k
+
+
+def test_f16x3_keeps_the_neighbour_sets(ops):
+    """kNN indices downstream of the f16x3 non-rigid offsets == those downstream of the fp32 offsets on the golden cases that
+    run the non-rigid MLP (wherever the fp32 kernel's own neighbour sets are not at a 1e-6 tie)."""
+    for name in ('freeview_amp_s32', 'freeview_trained_s32', 'freeview_trained_s128', 'movement_amp_s32_f3'):
+        g = util.load_golden(name)
+        ctx = util.model_context(int(g['meta.seed']), util.level(g))
+        W, B = util.nonrigid_params(ctx['sd'])
+        Wd, Bd = [T(w) for w in W], [T(b) for b in B]
+        packed, pf = ops.nonrigid_pack(Wd, Bd), ops.nonrigid_pack_f16(Wd)
+        xyz, cond, hann = T(g['nr.xyz_in']), T(g['nr.cond'].astype(np.float32).ravel()), np.ones(6, np.float32)
+        a = ops.nonrigid(xyz, cond, hann, Wd[0], Bd[0], packed)
+        b = ops.nonrigid_bf16x3(xyz, cond, hann, Wd[0], Bd[0], packed, pf)
+        m = _dev_model(ctx, ops)
+        ka = ops.msknn(a, m['points'], m['imap'], m['begin'], m['seed']).cpu().numpy()
+        kb = ops.msknn(b, m['points'], m['imap'], m['begin'], m['seed']).cpu().numpy()
+        diff = np.flatnonzero((ka != kb).reshape(ka.shape[0], -1).any(1))
+        print(f'\n   {name}: max |offset f16x3 - fp32| {float((a - b).abs().max()):.2e}; samples whose neighbour lists differ: {diff.size} of {ka.shape[0]}')
+        for i in diff:      # only genuine ties may differ
+            sets = [np.arange(ctx['point_base'].shape[0])] + [np.asarray(f) for f in ctx['fps']]
+            for lvl in range(4):
+                if not np.array_equal(ka[i, lvl], kb[i, lvl]):
+                    assert util.knn_mismatch_is_tie(a[i:i + 1].cpu().numpy(), ctx['point_base'], ka[i:i + 1, lvl], kb[i:i + 1, lvl], rel=2e-6)
+
+
 def test_autograd_path_matches_render_path(case):
     """With gradients enabled Network.forward takes the differentiable route (torch autograd over
     the HIP kNN and the HIP grid-encoder Function); in eval mode it must render the same image."""
@@ -1102,6 +1209,81 @@ def test_aggregate_autograd(ops):
     gw, = torch.autograd.grad(want, feats, gout, retain_graph=True)
     gg, = torch.autograd.grad(got, feats, gout)
     assert (gg - gw).abs().max().item() <= 1e-4 * gw.abs().max().item()
+    # runs (round 5): consecutive samples with identical id lists -- hence identical weights, which are a function of the ids
+    # -- are summed in registers and scattered once; samples with an all-zero gradient row are skipped.  Runs of every length
+    # across chunk (64) and trip (8) boundaries, a zero row inside a run, zero rows at both ends, against float64 autograd.
+    N2 = 5000
+    ids = torch.randint(0, P, (N2, K), device=DEV, dtype=torch.int32)
+    w2 = torch.softmax(torch.randn(N2, K, device=DEV), dim=1)
+    lens = [1, 2, 7, 8, 9, 63, 64, 65, 130, 500, 3, 1, 1000]
+    pos = 11
+    for ln in lens:
+        ids[pos:pos + ln] = ids[pos]
+        w2[pos:pos + ln] = w2[pos]
+        pos += ln + 2
+    gout2 = torch.randn(N2, Fd, device=DEV)
+    gout2[:11] = 0
+    gout2[700:705] = 0
+    gout2[-50:] = 0
+    gout2[40] = 0
+    f64 = feats.detach().double().requires_grad_(True)
+    want2 = (w2.double()[..., None] * f64[ids.long()]).sum(1)
+    gw2, = torch.autograd.grad(want2, f64, gout2.double())
+    f32 = feats.detach().clone().requires_grad_(True)
+    got2 = ops.aggregate(f32, ids, w2)
+    gg2, = torch.autograd.grad(got2, f32, gout2)
+    assert (gg2.double() - gw2).abs().max().item() <= 2e-6 * gw2.abs().max().item()
+
+
+def test_grid_grad_runs_merge(ops):
+    """occnerf_grid_grad_runs (the module backward's transposition [B, L*C] -> [L,B,C] with runs of bitwise identical inputs
+    merged) against the plain permutation: (a) with no identical neighbours the output IS the permutation, bit for bit;
+    (b) with runs of every length across the 64-sample chunk boundaries -- and -0.0 against +0.0, which are different bit
+    patterns and must not merge -- the embedding gradient of the full backward equals the unmerged one (float64 sum order
+    apart: 2e-6 of the largest entry), and every run's rows sit summed in its first sample with zeros behind."""
+    from occnerf_amd.gridencoder import grid_offsets
+    L, H, D, C = 16, 16, 4, 2
+    off, pls = grid_offsets(D, L, 2.0, H, 19, desired_resolution=2048 * 1.4)
+    S_ = float(np.log2(pls))
+    offsets = torch.tensor(np.asarray(off), dtype=torch.int32, device=DEV)
+    total = int(off[-1])
+    rng = np.random.default_rng(9)
+    B = 20000
+    x = rng.random((B, D), dtype=np.float32)
+    g = rng.standard_normal((B, L * C)).astype(np.float32)
+    plain = ops.grid_grad_runs(T(g), T(x), B, D, L, C)
+    assert torch.equal(plain, T(g).view(B, L, C).permute(1, 0, 2).contiguous())                      # (a)
+    pos, runs = 5, []
+    for ln in (2, 3, 63, 64, 65, 129, 700, 1, 2, 5000):
+        x[pos:pos + ln] = x[pos]
+        runs.append((pos, ln))
+        pos += ln + 3
+    x[pos, 0], x[pos + 1] = 0.0, x[pos]
+    x[pos + 1, 0] = -0.0                                                                             # not the same bits
+    xt, gt = T(x), T(g)
+    merged = ops.grid_grad_runs(gt, xt, B, D, L, C)
+    perm = gt.view(B, L, C).permute(1, 0, 2).contiguous()
+    for p0, ln in runs:
+        # inside a 64-sample chunk a run collapses onto its first sample; a run crossing chunk boundaries has one head per chunk
+        bounds = sorted({p0} | {b for b in range((p0 // 64 + 1) * 64, p0 + ln, 64)}) + [p0 + ln]
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            want = perm[:, a:b].double().sum(1)
+            assert float((merged[:, a].double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+            assert float(merged[:, a + 1:b].abs().max()) == 0.0 if b - a > 1 else True
+    assert torch.equal(merged[:, pos:pos + 2], perm[:, pos:pos + 2])
+    emb = torch.zeros(total, C, device=DEV)
+    ga, gb = torch.zeros(total, C, device=DEV), torch.zeros(total, C, device=DEV)
+    ops.grid_encode_backward(merged, xt, emb, offsets, ga, B, D, C, L, S_, H)
+    ops.grid_encode_backward(perm, xt, emb, offsets, gb, B, D, C, L, S_, H)
+    assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max())
+    # and through the module: encoder(x).backward(g) takes the merged route for B >= 4096
+    from occnerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=4, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                      desired_resolution=2048 * 1.4).to(DEV)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    enc(xt, bound=None).backward(gt)
+    assert float((enc.embeddings.grad - gb).abs().max()) <= 2e-6 * float(gb.abs().max())
 
 
 def test_grid_backward_tiled_vs_scatter(ops):

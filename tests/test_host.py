@@ -312,3 +312,41 @@ def test_forced_collective_and_plan_checksum_gloo(mode, world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_emulated_ranks_cover_the_frame(world):
+    """ShardedRenderer(emulate=(N, k)) -- what bench.py's `predicted_scaling` leg times while no multi-GPU node exists: every
+    rank k of N emulated in this process renders exactly the share the N-rank plan gives it (the union is the frame, each ray
+    once, shares balanced), writes it to ITS slot of the receive buffer, and rank 0's un-permutation puts those rays where the
+    caller's order wants them; ranks k > 0 return None like real ones.  Pipelined over frames with two camera names."""
+    from occnerf_amd.parallel import ShardedRenderer
+    g = torch.Generator().manual_seed(5)
+    n = 3000
+    data = {'rays': torch.rand(2, n, 3, generator=g), 'near': torch.rand(n, 1, generator=g), 'far': torch.rand(n, 1, generator=g)}
+    want = _FakeNet()(**data)
+    seen = torch.zeros(n, dtype=torch.int32)
+    sizes = []
+    for k in range(world):
+        r = ShardedRenderer(_FakeNet(), 'cpu', chunk=96, emulate=(world, k))
+        assert r.collective and r.world == world and r.rank == k and not r.verify_plan
+        outs = list(r.render_frames([(data, 'a'), (data, 'b'), (data, 'a')]))
+        plan = r._get_plan(data, 'a')
+        mine = plan['mine']['cpu']
+        assert int(seen[mine].sum()) == 0
+        seen[mine] += 1
+        sizes.append(plan['sizes'][k])
+        assert plan['sizes'][k] == mine.numel()
+        if k == 0:
+            for o in outs:      # rank 0 assembled the frame: its own rays are in place (the other slots are empty here)
+                assert torch.equal(o['rgb'][mine], want['rgb'][mine]) and torch.equal(o['alpha'][mine], want['alpha'][mine])
+                assert torch.equal(o['depth'][mine], want['depth'][mine])
+        else:
+            assert outs == [None, None, None]
+            full = r._bufs[plan['width']]['recv'][1].view(world, plan['width'], 5)      # rank k's block sits in slot k
+            blk = full[k, :mine.numel()]
+            assert torch.equal(blk[:, :3], want['rgb'][mine]) and torch.equal(blk[:, 4], want['depth'][mine])
+    assert bool((seen == 1).all())
+    assert max(sizes) <= 1.1 * (n / world) + 96
+    with pytest.raises(RuntimeError):
+        ShardedRenderer(_FakeNet(), 'cpu', emulate=(4, 4))

@@ -359,7 +359,7 @@ def test_hip_stages_match_torch_autograd_at_size():
                 {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None},
                 net.point_counter.detach().clone())
 
-    def torch_path(net_, rays8, Rs, Ts, vol, bmin, bsc, bg, cond, hann, t_rand_=None):
+    def torch_path(net_, rays8, Rs, Ts, vol, bmin, bsc, bg, cond, hann, t_rand_=None, point_block=None):
         dev = rays8.device
         return train_path.render_rays_autograd_torch(
             net_, rays8, Rs, Ts, vol, torch.as_tensor(bmin, device=dev), torch.as_tensor(bsc, device=dev),
@@ -537,3 +537,62 @@ def test_eval_render_sees_counter_moved_by_training_forward():
         want = fresh(**data, iter_val=1e7)['rgb']
     assert torch.equal(after, want)
     assert not torch.equal(after, before)
+
+
+def test_per_step_hipgraph_matches_eager_and_is_captured_once():
+    """the per-step static part (pose refiner, Rodrigues, motion bases, volume decoder, per-point SDF block)
+    replayed as two hipGraphs (occnerf_amd/train_graph.py) against the eager modules: identical kernels, so outputs and every
+    parameter gradient agree to reassociation noise of the few atomics in torch's index_put backward (1e-6 relative);
+    captured ONCE over five optimiser steps (in-place updates keep the data pointers), captured again after a
+    load_state_dict that replaces a parameter's storage."""
+    import warnings
+    from occnerf_amd import synth, train_graph
+    from occnerf_amd.optim import FusedAdam
+    frame = synth.make_frame(img_size=32, pose72=synth.seeded_pose(2), orbit_frame=7)
+    data = frame_to_device(frame, DEV)
+
+    def run(graph):
+        net, _ = build_network(0, True, S=32, non_rigid=True)
+        net.cfg.perturb, net.cfg.train_graph = 0.0, graph
+        net.train()
+        out = net(**data, iter_val=1e7)
+        loss = ((out['rgb'] - 0.5) ** 2).mean() + 0.5 * out['alpha'].mean() + 0.01 * out['depth'].mean() + 0.1 * out['comp_loss'].mean()
+        loss.backward()
+        return net, out, {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                        # a failed capture warns and falls back: here it must not
+        net_g, out_g, grads_g = run(True)
+    net_e, out_e, grads_e = run(False)
+    pg = train_graph.get(net_g)
+    assert pg.failed is None and pg.captures == 1 and pg.replays == 1
+    assert train_graph.get(net_e).replays == 0
+    for k in ('rgb', 'alpha', 'depth', 'comp_loss'):
+        assert torch.allclose(out_g[k], out_e[k], rtol=0, atol=1e-6), k
+    assert torch.equal(net_g.point_counter, net_e.point_counter)
+    assert sorted(grads_g) == sorted(grads_e)
+    for n in grads_e:
+        scale = float(grads_e[n].abs().max().clamp_min(1e-30))
+        assert float((grads_g[n] - grads_e[n]).abs().max()) <= 2e-5 * scale, n
+    for n in ('pose_decoder.block_mlps.0.weight', 'mweight_vol_decoder.const_embedding', 'point_dist'):
+        assert float(grads_g[n].abs().max()) > 0, n          # the graph's backward really reaches them
+    # five optimiser steps: no re-capture, the replayed forward follows the in-place weight updates
+    opt = FusedAdam([p for p in net_g.parameters() if p.requires_grad], lr=1e-3)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad(set_to_none=True)
+        out = net_g(**data, iter_val=1e7)
+        loss = ((out['rgb'] - 0.5) ** 2).mean() + 0.1 * out['comp_loss'].mean()
+        loss.backward()
+        opt.step(max_grad_norm=1.0)
+        losses.append(float(loss))
+    assert pg.captures == 1 and pg.replays == 6
+    assert losses[-1] < losses[0]
+    # before the kick-in iteration the pose refiner is off: another (captured once) graph
+    net_g(**data, iter_val=10.0)['rgb'].sum().backward()
+    assert pg.captures == 2
+    # a parameter whose storage was replaced -> captured again, once
+    sd = {k: v.clone() for k, v in net_g.state_dict().items()}
+    net_g.pose_decoder.block_mlps[0].weight = torch.nn.Parameter(sd['pose_decoder.block_mlps.0.weight'].clone())
+    net_g(**data, iter_val=1e7)['rgb'].sum().backward()
+    net_g(**data, iter_val=1e7)['rgb'].sum().backward()
+    assert pg.captures == 3
