@@ -40,7 +40,9 @@ const char *occnerf_last_error(void);
  * is read from its environment variable once, at first use, and clamped to its valid range; this call reads (value < 0) or
  * sets it afterwards.  Names: "cohab_lds" (OCCNERF_COHAB_LDS, bytes of padding LDS, 0..131072), "features_small"
  * (OCCNERF_FEATURES_SMALL, 0/1), "features_rowcache" (OCCNERF_FEATURES_ROWCACHE, 0/1), "agg_slices" (OCCNERF_AGG_SLICES,
- * 0 = automatic, else the sample slices of occnerf_agg_backward).  Returns the previous value, -1 for an
+ * 0 = automatic, else the sample slices of occnerf_agg_backward), "grid_xcd" (OCCNERF_GRID_XCD: the operator-level D4C2
+ * forward with the level pairs dealt to the XCDs -- 0: from 32 768 samples up (the default), 1: always, 2: never;
+ * profiles/r05_xcd_levels.md).  Returns the previous value, -1 for an
  * unknown name.  No counterpart in the reference. */
 int occnerf_experiment_knob(const char *name, int value);
 
@@ -296,6 +298,12 @@ int occnerf_point_sdf(const float *point_cloud, const float *point_base, const d
  *   [encode((knn_base+bound)/(2 bound), clamp((sdf+0.2)/0.8,0,1)) (32), learnable xyz (3), 0, unused...].
  * h_offsets: optional HOST copy of offsets[L+1]; with it the kernel knows per level whether the
  * table is dense or a power-of-two hash and skips the generic 32-bit modulo (same indices). */
+/* Training step: gradient of the learnable point offsets point_dist[P] (network.py:109,119: point_cloud = point_base +
+ * point_dist, one offset per point added to all three coordinates) through occnerf_point_sdf -- network.py:263-284 under
+ * autograd -- from d_knn_base[P,3] (fp64) and d_dist[P]; kidx: the 3-NN ids of the forward (constants of the graph). */
+int occnerf_point_sdf_backward(const float *point_cloud, const float *point_base, const double *normals,
+                               const double *unit_normals, const int32_t *kidx, int32_t P, const double *d_knn_base,
+                               const float *d_dist, float *d_point_dist, void *stream);
 int32_t occnerf_point_table_stride(void);
 int occnerf_point_table(const double *knn_base, const float *point_sdf, const float *learnable,
                         int32_t P, float bound, float two_bound, const float *embeddings,

@@ -57,6 +57,7 @@ SIGNATURES = {
     'occnerf_point_sdf': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     'occnerf_ray_order_temp_bytes': (_i64, [_i64]),
     'occnerf_ray_order': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    'occnerf_point_sdf_backward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'occnerf_gen_rays': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_agg_forward': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     'occnerf_agg_backward_slices': (_i32, [_i64]),

@@ -10,28 +10,46 @@
 
 namespace occ {
 
+// (round 5) A wave takes kAggFwdRun consecutive samples: a sample whose 40 ids equal its predecessor's -- a run of collapsed
+// samples, see the backward below -- has the same weights (a function of the ids) and therefore the same sum: it is copied,
+// not gathered again.
+constexpr int kAggFwdRun = 8;
+
 __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restrict__ feats, int F,
                                                           const int32_t *__restrict__ knn,
                                                           const float *__restrict__ atts, int64_t N, int K,
                                                           float *__restrict__ agg) {
     const int lane = threadIdx.x & 63;
-    const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (n >= N) return;
-    const int32_t *id = knn + n * K;
-    const float *w = atts + n * K;
+    const int64_t n0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kAggFwdRun;
+    if (n0 >= N) return;
+    const int64_t n1 = n0 + kAggFwdRun < N ? n0 + kAggFwdRun : N;
+    int prev_id = -2;
     float acc = 0.0f;
-    for (int j0 = 0; j0 < K; j0 += 64) {                       // ids / weights of up to 64 neighbours at once
-        const int jj = j0 + lane;
-        const int my_id = jj < K ? id[jj] : 0;
-        const float my_w = jj < K ? w[jj] : 0.0f;
-        const int cnt = K - j0 < 64 ? K - j0 : 64;
-        for (int j = 0; j < cnt; j++) {
-            const int p = __shfl(my_id, j);
-            const float wj = __shfl(my_w, j);
-            if (lane < F) acc = __fadd_rn(acc, __fmul_rn(wj, ld32(feats, ((uint32_t)p * (uint32_t)F + (uint32_t)lane) * 4u)));
+    for (int64_t n = n0; n < n1; n++) {
+        const int32_t *id = knn + n * K;
+        const float *w = atts + n * K;
+        bool same = K <= 64;
+        if (same) {
+            const int my = lane < K ? id[lane] : -1;
+            same = __builtin_amdgcn_ballot_w64(my != prev_id) == 0ull;
+            prev_id = my;
         }
+        if (!same) {
+            acc = 0.0f;
+            for (int j0 = 0; j0 < K; j0 += 64) {                       // ids / weights of up to 64 neighbours at once
+                const int jj = j0 + lane;
+                const int my_id = jj < K ? id[jj] : 0;
+                const float my_w = jj < K ? w[jj] : 0.0f;
+                const int cnt = K - j0 < 64 ? K - j0 : 64;
+                for (int j = 0; j < cnt; j++) {
+                    const int p = __shfl(my_id, j);
+                    const float wj = __shfl(my_w, j);
+                    if (lane < F) acc = __fadd_rn(acc, __fmul_rn(wj, ld32(feats, ((uint32_t)p * (uint32_t)F + (uint32_t)lane) * 4u)));
+                }
+            }
+        }
+        if (lane < F) agg[n * F + lane] = acc;
     }
-    if (lane < F) agg[n * F + lane] = acc;
 }
 
 // Backward.  Global fp32 atomics are memory-side operations on this part (~20 G/s even on a 1 MB table:
@@ -172,7 +190,7 @@ OCC_API int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *kn
     if (N <= 0) return 0;
     OCC_REQUIRE(feats && knn && atts && agg, "agg_forward: null argument");
     OCC_REQUIRE(F >= 1 && F <= 64 && K >= 1, "agg_forward: F=%d (1..64), K=%d", F, K);
-    const int64_t blocks = (N + 3) / 4;
+    const int64_t blocks = ((N + kAggFwdRun - 1) / kAggFwdRun + 3) / 4;
     OCC_REQUIRE(blocks < (1ll << 31), "agg_forward: N too large");
     hipLaunchKernelGGL(agg_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), feats, F, knn, atts,
                        N, K, agg);

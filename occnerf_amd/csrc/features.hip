@@ -84,6 +84,55 @@ __global__ void point_sdf_kernel(const float *__restrict__ point_cloud,
     dist[i] = d;
 }
 
+// Backward of point_sdf_kernel w.r.t. the point offsets (training: network.py:263-284 under autograd; point_cloud =
+// point_base + point_dist with the [P,1] offset broadcast over xyz, network.py:119): given d knn_base[P,3] (fp64) and
+// d dist[P], the gradient of point_dist[P].  The neighbour ids, the normals and point_base are constants of the graph.
+//   dist = +-mean_j |dir_j|                       -> d dir_j += (+-d dist / 3) dir_j / |dir_j|
+//   knn_base = sum att_j nbr_j / sum att_j        -> d att_j = d knn_base . (nbr_j - knn_base) / sum att
+//   att_j = |c_j|, c_j = (dir_j/|dir_j|) . un_j   -> d dir_j += sign(c_j) d att_j (un_j - c_j dir_j/|dir_j|) / |dir_j|
+//   dir_j = pc - nbr_j, pc = base + dist 1        -> d point_dist = sum_c sum_j d dir_j[c]
+// torch autograd takes ~70 tiny launches for it per step; fp64 throughout (6 890 threads).
+__global__ void point_sdf_backward_kernel(const float *__restrict__ point_cloud, const float *__restrict__ point_base,
+                                          const double *__restrict__ normals, const double *__restrict__ unit,
+                                          const int32_t *__restrict__ kidx, int P, const double *__restrict__ d_knn_base,
+                                          const float *__restrict__ d_dist, float *__restrict__ d_point_dist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    double dir[3][3], nd[3], c[3], att[3], nbr[3][3], num[3] = {0.0, 0.0, 0.0}, den = 0.0;
+    int neg = 0;
+    for (int j = 0; j < 3; j++) {
+        const int n = kidx[i * 3 + j];
+        float df[3];
+        for (int k = 0; k < 3; k++) {
+            df[k] = __fsub_rn(point_cloud[i * 3 + k], point_base[n * 3 + k]);
+            dir[j][k] = (double)df[k];
+            nbr[j][k] = (double)point_base[n * 3 + k];
+        }
+        float na = norm3(df[0], df[1], df[2]);
+        nd[j] = (double)(na < 1e-8f ? 1e-8f : na);
+        c[j] = (dir[j][0] * unit[n * 3] + dir[j][1] * unit[n * 3 + 1] + dir[j][2] * unit[n * 3 + 2]) / nd[j];
+        att[j] = fabs(c[j]);
+        for (int k = 0; k < 3; k++) num[k] += att[j] * nbr[j][k];
+        den += att[j];
+        const float n0 = (float)normals[n * 3], n1 = (float)normals[n * 3 + 1], n2 = (float)normals[n * 3 + 2];
+        neg += __fadd_rn(__fadd_rn(__fmul_rn(df[0], n0), __fmul_rn(df[1], n1)), __fmul_rn(df[2], n2)) < 0.0f;
+    }
+    const double gd = (double)d_dist[i] * (neg > 1 ? -1.0 : 1.0) / 3.0;
+    double g = 0.0;
+    for (int j = 0; j < 3; j++) {
+        const int n = kidx[i * 3 + j];
+        double datt = 0.0;
+        for (int k = 0; k < 3; k++) datt += d_knn_base[i * 3 + k] * (nbr[j][k] - num[k] / den);
+        datt /= den;
+        const double dc = c[j] < 0.0 ? -datt : (c[j] > 0.0 ? datt : 0.0);
+        for (int k = 0; k < 3; k++) {
+            const double u = dir[j][k] / nd[j];
+            g += gd * u + dc * (unit[n * 3 + k] - c[j] * u) / nd[j];
+        }
+    }
+    d_point_dist[i] = (float)g;
+}
+
 __global__ void point_table_kernel(const double *__restrict__ knn_base,
                                    const float *__restrict__ point_sdf,
                                    const float *__restrict__ learnable, int P, float bound,
@@ -352,7 +401,7 @@ __global__ void point_pack_kernel(const float *__restrict__ point_base, const do
 // ---------------------------------------------------------------------------------------
 // sample_features, 8 lanes per sample.  The thread-per-sample kernel above keeps the memory
 // pipeline (TA) 98 % busy with ~700 line look-ups per sample, one per lane per instruction, and
-// writes its 272-byte rows in partial lines (3x write amplification, profiles/r01_pmc_hbm.json).
+// writes its 272-byte rows in partial lines (3x write amplification, profiles/archive/r01_pmc_hbm.json).
 // Here a sample is owned by 8 consecutive lanes:
 //   * a table row's 32 encoding features are one float4 per lane = 128 contiguous bytes (2 line
 //     look-ups instead of 8), the 3-float tail goes to lane j & 7;
@@ -417,7 +466,7 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
     __shared__ float4 s_tail[LDS_TAIL ? kLdsTailPoints : 1];
     // Output timing (round 4).  A sample's 272-byte row of mlp_in is written in three 16-byte-per-lane pieces; the encoding
     // half used to leave half-way through the trip and the aggregate at its end, ~1 us apart, and L2 evicted half-written
-    // lines in between: WRITE_SIZE was 1.26x the 276 B/sample the kernel produces (profiles/r03_pmc_hbm.json).  The
+    // lines in between: WRITE_SIZE was 1.26x the 276 B/sample the kernel produces (profiles/archive/r03_pmc_hbm.json).  The
     // encoding piece now waits in a lane-private LDS slot (no registers held across the row phase) and the three stores
     // leave back to back at the end of the trip.
     __shared__ float4 s_out[LDS_TAIL ? 768 : 256];
@@ -749,7 +798,7 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
 // The (tail, count) image of all points in LDS shrinks to the counts (the tails arrive with the rows).  Arithmetic and
 // summation order are those of sample_features8_kernel: bit-identical outputs (tested against it on the benchmark frame).
 //
-// MEASURED (round 3, benchmark frame, 17.6 M rows; profiles/r03_features_rowcache.md): bit-identical and SLOWER,
+// MEASURED (round 3, benchmark frame, 17.6 M rows; profiles/archive/r03_features_rowcache.md): bit-identical and SLOWER,
 // 12.6 ms against 10.0 ms, so it is OPT-IN (OCCNERF_FEATURES_ROWCACHE=1) and the renderer keeps sample_features8_kernel.
 // Gather instructions per trip fall 83 -> 71 only (one trip in five has more than 56 distinct rows and falls back), the
 // texture path stays as busy (TA busy 1.80e7 vs 1.74e7 cycles per XCD: LDS-DMA pieces pay the texture path too, and land
@@ -1116,6 +1165,20 @@ OCC_API int occnerf_point_sdf(const float *point_cloud, const float *point_base,
     hipLaunchKernelGGL(point_sdf_kernel, dim3((P + 255) / 256), dim3(256), 0, as_stream(stream), point_cloud,
                        point_base, normals, unit_normals, kidx, P, knn_base, dist);
     return check_launch("point_sdf");
+}
+
+/* Gradient of point_dist[P] (the [P,1] offset added to every coordinate of point_base, network.py:119) through
+ * occnerf_point_sdf, from d_knn_base[P,3] (fp64) and d_dist[P]; kidx = the same 3-NN ids the forward used. */
+OCC_API int occnerf_point_sdf_backward(const float *point_cloud, const float *point_base, const double *normals,
+                                       const double *unit_normals, const int32_t *kidx, int32_t P, const double *d_knn_base,
+                                       const float *d_dist, float *d_point_dist, void *stream) {
+    using namespace occ;
+    OCC_REQUIRE(point_cloud && point_base && normals && unit_normals && kidx && d_knn_base && d_dist && d_point_dist,
+                "point_sdf_backward: null argument");
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(point_sdf_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, as_stream(stream), point_cloud, point_base,
+                       normals, unit_normals, kidx, P, d_knn_base, d_dist, d_point_dist);
+    return check_launch("point_sdf_backward");
 }
 
 OCC_API int32_t occnerf_point_table_stride(void) { return occ::kTableStride; }

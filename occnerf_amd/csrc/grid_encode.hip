@@ -130,6 +130,40 @@ __global__ __launch_bounds__(256) void grid_forward_kernel(
     }
 }
 
+// Round 5 (knob "grid_xcd"): the same encoder with the LEVELS dealt to the XCDs.  Workgroups are
+// dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own 4 MiB L2, and a hashed level is a 4 MiB
+// table: in the sample-major kernels every XCD's L2 sees all 16 levels (59 MiB).  Here block b serves level pair b % 8 for the
+// samples of chunk b / 8 -- one thread per sample, both levels of the pair -- so an XCD's L2 holds 2 levels.  The price: every
+// sample's 16-byte input is read by 8 workgroups, and the outputs only come out level-major ([L,B,C], the operator's layout;
+// the renderer's feature kernel wants them inside a sample-major 272-byte row).  Same bits.  Measured against the sample-major
+// kernel on the benchmark frame's 17.6 M encoder inputs (profiles/r05_xcd_levels.md): 5.31 against 8.59 ms, FETCH_SIZE 5.3
+// against 10.5 GB -- so the OPERATOR (training step, per-point table) uses it for large batches; the renderer's fused feature
+// kernel keeps its layout (after the centre shortcuts a third of its samples still encode, ~0.5-1 ms of its 7.8: a separate
+// XCD-dealt pass for them would cost more than it saves).
+__global__ __launch_bounds__(256) void grid_forward_d4c2_xcd_kernel(const float4 *__restrict__ inputs,
+                                                                    const float2 *__restrict__ embeddings,
+                                                                    const int32_t *__restrict__ offsets,
+                                                                    float2 *__restrict__ outputs, uint32_t B, uint32_t L,
+                                                                    GridLevels lv, GridModes4 gm) {
+    const uint32_t pair = blockIdx.x & 7u;
+    const uint32_t b = (blockIdx.x >> 3) * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float4 xv = inputs[b];
+    const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+    const bool oob = x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f || x[2] < 0.f || x[2] > 1.f || x[3] < 0.f || x[3] > 1.f;
+#pragma unroll
+    for (uint32_t u = 0; u < 2; u++) {
+        const uint32_t l = 2 * pair + u;
+        if (l >= L) continue;
+        float2 v = make_float2(0.f, 0.f);
+        if (!oob) {
+            const uint32_t o0 = (uint32_t)offsets[l];
+            v = encode_level_d4c2(x, embeddings, (uint32_t)offsets[l + 1] - o0, lv.scale[l], lv.resolution[l], gm.mode[l], o0);
+        }
+        outputs[(size_t)l * B + b] = v;
+    }
+}
+
 // The encoder the canonical MLP uses (D = 4, C = 2, hash grid, linear interpolation, no input gradient), shaped for
 // this machine instead of the reference's thread-per-(sample, level) grid: 8 lanes share a sample and take 2 levels
 // each (occ::encode_level_d4c2: shared partial corner weights, per-level index mode decided on the HOST -- dense /
@@ -532,6 +566,15 @@ static int grid_forward_impl(const float *inputs, const float *embeddings, const
         uint32_t sizes[kMaxLevels] = {0};
         for (uint32_t l = 0; l < L; l++) sizes[l] = (uint32_t)(h_off[l + 1] - h_off[l]);
         const GridModes4 gm = make_grid_modes_d4(L, lv, sizes);
+        // level pairs dealt to the XCDs (see the kernel): measured 1.6x faster with half the fabric fetches on large batches
+        // (profiles/r05_xcd_levels.md), same bits -- the default from 32 768 samples up (knob grid_xcd: 1 always, 2 never)
+        const int xk = knob(kKnobGridXcd);
+        if (xk == 1 || (xk == 0 && B >= 32768u)) {
+            hipLaunchKernelGGL(grid_forward_d4c2_xcd_kernel, dim3(((B + 255) / 256) * 8), dim3(256), 0, st,
+                               reinterpret_cast<const float4 *>(inputs), reinterpret_cast<const float2 *>(embeddings), offsets,
+                               reinterpret_cast<float2 *>(outputs), B, L, lv, gm);
+            return check_launch("grid_encode_forward");
+        }
         const uint32_t threads = B * 8;
         hipLaunchKernelGGL(grid_forward_d4c2_kernel, dim3((threads + 255) / 256), dim3(256), 0, st,
                            reinterpret_cast<const float4 *>(inputs), reinterpret_cast<const float2 *>(embeddings), offsets,

@@ -517,8 +517,19 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, const float 
         const int n = idx / k_pad, k = idx - n * k_pad;
         const int rn = row_map[n], ck = col_map[k];
         if (rn >= 0 && ck >= 0) {
-            double s = 0.0;
-            for (int g = 0; g < G; g++) s += (double)part[(int64_t)g * nk + idx];
+            // eight independent partial sums: the 256 loads of a thread are 256 KiB apart, and with one dependent chain
+            // only a handful were in flight (64 MB in 67 us); same fixed summation order for every element: deterministic
+            double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            int g = 0;
+            for (; g + 8 <= G; g += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = part[(int64_t)(g + u) * nk + idx];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s8[u] += (double)v[u];
+            }
+            for (; g < G; g++) s8[0] += (double)part[(int64_t)g * nk + idx];
+            const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
             float *o = dW + (int64_t)rn * in_dim + ck;
             *o = (float)(accumulate ? (double)*o + s : s);
         }

@@ -315,6 +315,24 @@ class Network(nn.Module):
         st['mlp_in'] = None
         return ops.composite(raw, st['mask'], st['z'], st['rays8'], bgcolor, out=out, out_rows=out_rows)[:3]
 
+    def _nonrigid_f16_pack(self):
+        """Split-fp16 operand stream of the non-rigid MLP for the bf16 training step (kept beside the fp32 pack, same key)."""
+        pk = self._packed_weights()
+        if pk.get('nr_f16_train') is None:
+            nr_lin = [m for m in self.non_rigid_mlp.module.block_mlps if isinstance(m, nn.Linear)]
+            pk['nr_f16_train'] = pk['nr_bf16'] if (pk['nr_bf16'] is not None and pk['nr_bf16'].dtype == torch.float16) else \
+                ops.nonrigid_pack_f16([m.weight.detach() for m in nr_lin])
+        return pk['nr_f16_train']
+
+    def _knn_center_lists(self, cond, hann):
+        """(center[4], idx[4,10]) of ops.knn_center at this frame's collapse point (see _knn_center): what the kNN kernel's
+        centre cache takes -- without the cached feature row the renderer adds."""
+        ctx, pk = self._context(), self._packed_weights()
+        c = torch.zeros(64, 3, device=self.point_base.device)
+        if not self.cfg.ignore_non_rigid_motions:
+            c = ops.nonrigid(c, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], direct=True)
+        return ops.knn_center(c[0].contiguous(), ctx['points'], ctx['index_map'], ctx['scale_begin'])
+
     def _knn_center(self, cond, hann, table, pack):
         """(center, idx) of ops.knn_center for this frame's collapse point: wherever a sample's motion-weight sum is far below
         the 1e-4 clamp of the reference's warp (network.py:388) its warped position lands within a micrometre of the origin,

@@ -360,3 +360,38 @@ def pose_motion_bases(pose_decoder, posevec, dst_Rs, dst_Ts, cnl_gtfms):
     if len(lin) != 5 or lin[0].in_features != 69 or lin[0].out_features != 256 or lin[4].out_features != 69:
         raise RuntimeError('pose_motion_bases: the fused kernels are built for the 69 -> 256 x4 -> 69 refiner of occnerf.yaml')
     return _PoseMotionBases.apply(posevec, dst_Rs, dst_Ts, cnl_gtfms, *[m.weight for m in lin], *[m.bias for m in lin])
+
+
+# ------------------------------------------------------------------ per-point SDF block
+class _PointSdf(Function):
+    """point_dist[P,1] -> knn_base[P,3] (fp64), sdf[P,1] of network.py:263-284: the renderer's forward kernels (3-NN search +
+    occnerf_point_sdf) and one backward kernel (occnerf_point_sdf_backward) -- 3 launches where torch autograd takes ~100."""
+
+    @staticmethod
+    def forward(ctx, point_dist, point_base, normals, unit):
+        pc = (point_base + point_dist).float().contiguous()
+        kidx = ops.knn_small(pc, point_base, 3)
+        kb, sdf = ops.point_sdf(pc, point_base, normals, unit, kidx)
+        ctx.save_for_backward(pc, point_base, normals, unit, kidx)
+        ctx.dist_shape = tuple(point_dist.shape)
+        return kb, sdf[:, None]
+
+    @staticmethod
+    def backward(ctx, d_kb, d_sdf):
+        pc, base, normals, unit, kidx = ctx.saved_tensors
+        P = pc.shape[0]
+        d_kb = (torch.zeros(P, 3, device=pc.device, dtype=torch.float64) if d_kb is None else d_kb.double()).contiguous()
+        d_sdf = (torch.zeros(P, device=pc.device) if d_sdf is None else d_sdf.reshape(-1).float()).contiguous()
+        out = torch.empty(P, device=pc.device, dtype=torch.float32)
+        with ops._guard(pc):
+            rc = _lib.lib().occnerf_point_sdf_backward(pc.data_ptr(), base.data_ptr(), normals.data_ptr(), unit.data_ptr(),
+                                                       kidx.data_ptr(), P, d_kb.data_ptr(), d_sdf.data_ptr(), out.data_ptr(),
+                                                       ops._stream(pc))
+        _lib.check(rc, 'point_sdf_backward')
+        return out.reshape(ctx.dist_shape), None, None, None
+
+
+def point_sdf(net):
+    """(knn_base[P,3] fp64, sdf[P,1]) of the network's point cloud with the gradient to net.point_dist."""
+    ctx = net._context()
+    return _PointSdf.apply(net.point_dist, net.point_base.detach().float().contiguous(), ctx['normals'], ctx['unit'])

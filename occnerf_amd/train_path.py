@@ -78,7 +78,11 @@ def motion_bases(net, refine, posevec, dst_Rs, dst_Ts, cnl_gtfms):
 
 
 def point_sdf_block(net):
-    """network.py:263-284 with gradients to point_dist -> knn_base[P,3] (f64), dist[P,1]."""
+    """network.py:263-284 with gradients to point_dist -> knn_base[P,3] (f64), dist[P,1].  Default: the renderer's forward
+    kernels + one backward kernel (train_ops.point_sdf); cfg.train_fused_points=False: the torch ops under autograd, kept as
+    the reference the fused pair is tested against."""
+    if net.cfg.get('train_fused_points', True) and net.point_base.is_cuda:
+        return train_ops.point_sdf(net)
     pc = net.point_cloud.float()
     base = net.point_base.detach()
     kidx = ops.knn_small(pc.detach().contiguous(), base, 3).long()
@@ -283,12 +287,21 @@ def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor,
         z, cnl, mask = train_ops.sample_warp(rays8, S, t_vals, t_rand, Rs.float(), Ts.float(), vol.float(), bbox_min,
                                              bbox_scale)
     xyz = cnl
-    if not cfg.ignore_non_rigid_motions:
-        pk = net._packed_weights()
-        with torch.no_grad():
-            xyz = ops.nonrigid(cnl, cond.reshape(-1).float().contiguous(), hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
+    center = None
     with torch.no_grad():
-        knn = ops.msknn_clustered(xyz, n, S, ctx['clusters'], ctx['seed'])
+        if not cfg.ignore_non_rigid_motions:
+            pk = net._packed_weights()
+            condv = cond.reshape(-1).float().contiguous()
+            if bf16 and cfg.get('train_nonrigid_f16x3', True):
+                # bf16 step: the offsets (no gradient reaches this MLP, occnerf_mlp.py:144-167) on the fp32-grade split-fp16
+                # kernels (csrc/split.h; <= 1e-6 m from the fp32 kernel, 2.6x faster)
+                xyz = ops.nonrigid_bf16x3(cnl, condv, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], net._nonrigid_f16_pack())
+            else:
+                xyz = ops.nonrigid(cnl, condv, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
+        if cfg.get('knn_center_cache', True) and cfg.get('knn_culling', True):
+            # the renderer's exact centre cache: queries inside the proven radius around the collapse point take its lists
+            center = net._knn_center_lists(cond.reshape(-1).float().contiguous(), hann)
+        knn = ops.msknn_clustered(xyz, n, S, ctx['clusters'], ctx['seed'], center=center)
     with torch.autocast('cuda', enabled=False):
         knn_base, sdf = point_sdf_block(net) if point_block is None else point_block
         raw = canonical_mlp_hip(net.cnl_mlp.module, xyz, knn, net, knn_base, sdf, ctx, bf16)

@@ -1231,6 +1231,7 @@ def test_aggregate_autograd(ops):
     gw2, = torch.autograd.grad(want2, f64, gout2.double())
     f32 = feats.detach().clone().requires_grad_(True)
     got2 = ops.aggregate(f32, ids, w2)
+    assert (got2.double() - want2).abs().max().item() <= 2e-6          # (the forward copies a run's sum instead of gathering again)
     gg2, = torch.autograd.grad(got2, f32, gout2)
     assert (gg2.double() - gw2).abs().max().item() <= 2e-6 * gw2.abs().max().item()
 
@@ -1911,7 +1912,7 @@ def test_two_process_sharded_movement_at_size():
 def test_feature_kernel_row_cache_variant_is_bit_identical(ops):
     """The opt-in per-wave row cache of the feature kernel (OCCNERF_FEATURES_ROWCACHE=1 / occnerf_experiment_knob: distinct table rows of a wave trip
     staged in LDS by LDS-DMA, csrc/features.hip sample_features8r_kernel) against the shipped kernel on a 256x256 x 128 frame:
-    the 68-float MLP input rows and the signed distances bit for bit (it is slower, hence opt-in: profiles/r03_features_rowcache.md)."""
+    the 68-float MLP input rows and the signed distances bit for bit (it is slower, hence opt-in: profiles/archive/r03_features_rowcache.md)."""
     from occnerf_amd import synth
     net, ctx = build_network(seed=0, amplify=True, S=128, non_rigid=True)
     net.cfg.dedup_repeated_samples = False

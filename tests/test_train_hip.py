@@ -596,3 +596,39 @@ def test_per_step_hipgraph_matches_eager_and_is_captured_once():
     net_g(**data, iter_val=1e7)['rgb'].sum().backward()
     net_g(**data, iter_val=1e7)['rgb'].sum().backward()
     assert pg.captures == 3
+
+
+def test_fused_pose_chain_and_point_block_match_torch_autograd():
+    """The two fused backward kernels of round 5 -- pose refiner -> Rodrigues -> forward kinematics -> inverse -> motion bases
+    (csrc/preamble.hip pose_motion_bases_backward_kernel) and the per-point SDF block (csrc/features.hip
+    point_sdf_backward_kernel) -- against torch autograd over the torch modules / ops they replace (cfg.train_fused_pose /
+    train_fused_points off): every output and every parameter gradient of a training forward + backward, on the amplified
+    checkpoint (visible pose corrections and point offsets).  The fused forward inverts the bone transforms in closed form where
+    torch runs an LU (1e-7 apart), so outputs agree to 1e-5 and gradients to 2e-5 of their largest entry."""
+    from occnerf_amd import synth
+    frame = synth.make_frame(img_size=32, pose72=synth.seeded_pose(2), orbit_frame=7)
+    data = frame_to_device(frame, DEV)
+
+    def run(fused):
+        net, _ = build_network(0, True, S=32, non_rigid=True)
+        net.cfg.perturb, net.cfg.train_graph = 0.0, False
+        net.cfg.train_fused_pose = net.cfg.train_fused_points = fused
+        net.train()
+        out = net(**data, iter_val=1e7)
+        loss = ((out['rgb'] - 0.5) ** 2).mean() + 0.5 * out['alpha'].mean() + 0.01 * out['depth'].mean() + 0.1 * out['comp_loss'].mean()
+        loss.backward()
+        return out, {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    out_f, g_f = run(True)
+    out_t, g_t = run(False)
+    for k in ('rgb', 'alpha', 'depth', 'comp_loss'):
+        assert float((out_f[k] - out_t[k]).abs().max()) <= (1e-4 if k == 'comp_loss' else 1e-5), k      # (O(1) hash features behind the 1e-7)
+    assert sorted(g_f) == sorted(g_t)
+    worst = {}
+    for n in g_t:
+        scale = float(g_t[n].abs().max().clamp_min(1e-30))
+        worst[n] = float((g_f[n] - g_t[n]).abs().max()) / scale
+    focus = {n: f'{v:.1e}' for n, v in worst.items() if n.startswith('pose_decoder') or n == 'point_dist'}
+    print(focus)
+    assert len([n for n in focus if n.startswith('pose_decoder')]) == 10 and 'point_dist' in focus
+    for n, v in worst.items():
+        assert v <= 2e-5, (n, v)

@@ -3,7 +3,7 @@
 # HBM traffic per launch of every occ:: kernel of the bench frame: two separate --pmc passes
 # (FETCH_SIZE, WRITE_SIZE; never combined with trace domains), per MI355X_MICROARCH.md's HBM section:
 # counter values are KiB; FETCH_SIZE x2 for wide coalesced reads on gfx950; WRITE_SIZE uncorrected.  The x2 holds for wide
-# coalesced streams only (tools/fetch_calib.hip, profiles/r03_fetch_calibration.md: a gather's L2 miss is one 64-byte fabric
+# coalesced streams only (tools/fetch_calib.hip, profiles/archive/r03_fetch_calibration.md: a gather's L2 miss is one 64-byte fabric
 # request and is reported at face value), so every kernel gets ONE traffic figure with the factor of its access pattern:
 # x1 for the gather kernels (hash corners, table rows, kNN points, motion-volume taps), x2 for the streaming ones.
 out=$1
@@ -33,7 +33,7 @@ res = {'source': 'tools/pmc_hbm.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZ
                  'bench.py --steps 2 --warmup 1 on MI355X',
        'units': 'counter values are KiB per launch (mean over the launches); hbm_bytes_corrected = fetch_factor x FETCH_SIZE + '
                 'WRITE_SIZE with fetch_factor 2 for kernels that stream wide coalesced reads (MI355X_MICROARCH.md, HBM section) '
-                'and 1 for the gather kernels (profiles/r03_fetch_calibration.md: 64-byte gather misses are counted at face value)',
+                'and 1 for the gather kernels (profiles/archive/r03_fetch_calibration.md: 64-byte gather misses are counted at face value)',
        'samples_per_launch': n, 'kernels': {}}
 for k, c in acc.items():
     f = sum(c['FETCH_SIZE']) / max(len(c['FETCH_SIZE']), 1)
