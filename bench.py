@@ -43,6 +43,13 @@ branch of the sharded renderer with a ONE-rank `nccl` process group (plan + chec
 asynchronous dist.gather on device buffers, work.wait(), un-permutation): what a single-GPU box can execute of the
 multi-GPU path; pixels bit-identical to the headline's, never part of `value`.  It runs in a CHILD process under a time limit
 (this script again with a few headline frames of its own), so that a communicator that hangs cannot take the headline line down.
+Round 5: `alt2` -- the fp32-GRADE split-fp16 MLP path (cfg.mlp_precision='f16x3'; its kernel's launches timed with HIP events);
+`predicted_scaling` -- PREDICTED, SINGLE GPU, not a scaling curve: inside the rccl_world1 child every rank k of the N-rank plans
+(N = 2, 4, 8) of the headline frame is emulated through the collective renderer (ShardedRenderer(emulate=(N, k)), RCCL self-gather
+into slot k) and {N, slowest_rank_ms, T1_over_slowest, per_rank_fixed_ms} reported; `freeview_orbit` -- 8 consecutive frames of
+the orbit, a NEW camera every frame (nothing named or cached: device ray generation, Morton order, render, image assembly, uint8
+D2H), with the per-frame cost of the order shown separately; `train.roofline` -- the training step against the compulsory HBM
+traffic of its staged design (per-row byte table in this file) and the bf16 MFMA floor.
 """
 import argparse
 import json

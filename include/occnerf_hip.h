@@ -42,7 +42,8 @@ const char *occnerf_last_error(void);
  * (OCCNERF_FEATURES_SMALL, 0/1), "features_rowcache" (OCCNERF_FEATURES_ROWCACHE, 0/1), "agg_slices" (OCCNERF_AGG_SLICES,
  * 0 = automatic, else the sample slices of occnerf_agg_backward), "grid_xcd" (OCCNERF_GRID_XCD: the operator-level D4C2
  * forward with the level pairs dealt to the XCDs -- 0: from 32 768 samples up (the default), 1: always, 2: never;
- * profiles/r05_xcd_levels.md).  Returns the previous value, -1 for an
+ * profiles/r05_xcd_levels.md), "linear_resident" (OCCNERF_LINEAR_RESIDENT: 1 / 2 = the weight-resident persistent forms of
+ * occnerf_linear_forward with 4 / 8 waves -- both measured slower than the shipped kernel, csrc/linear.hip).  Returns the previous value, -1 for an
  * unknown name.  No counterpart in the reference. */
 int occnerf_experiment_knob(const char *name, int value);
 

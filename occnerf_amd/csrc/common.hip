@@ -28,7 +28,8 @@ static const KnobSpec kKnobSpecs[kKnobCount] = {{"cohab_lds", "OCCNERF_COHAB_LDS
                                                 {"features_small", "OCCNERF_FEATURES_SMALL", 0, 1},
                                                 {"features_rowcache", "OCCNERF_FEATURES_ROWCACHE", 0, 1},
                                                 {"agg_slices", "OCCNERF_AGG_SLICES", 0, 1024},
-                                                {"grid_xcd", "OCCNERF_GRID_XCD", 0, 2}};
+                                                {"grid_xcd", "OCCNERF_GRID_XCD", 0, 2},
+                                                {"linear_resident", "OCCNERF_LINEAR_RESIDENT", 0, 2}};
 static std::atomic<int> g_knob[kKnobCount];
 static std::atomic<bool> g_knob_read[kKnobCount];
 

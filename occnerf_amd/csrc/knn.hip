@@ -511,39 +511,54 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     }
 }
 
-// Small generic kNN (k <= 16), one query per thread, lists in registers via a fixed-size
-// unrolled insertion; used for the per-point k=3 search and the k=10 visibility update.
-template <int K>
+// Small generic kNN (k <= 16): LQ lanes per query (8, or a whole wave), lists in registers via a fixed-size unrolled
+// insertion; used for the per-point k=3 search and the k=10 visibility update.  Lane g scans support rows g, g + LQ, ...
+// (four rows' loads in flight per trip) into its own sorted list of fp64 (distance, row) keys (see KBest64), then the LQ
+// lists are merged by butterfly exchange.  The key order is the (distance, row) order, i.e. exactly "strict '<' in row
+// order" of the serial scan: the result does not depend on LQ.  (Round 5: with 8 lanes per query the P x P search of the
+// training step's per-point block was 862 single-wave blocks of 861 dependent trips -- 0.26 ms; a wave per query: 6 890 waves
+// of 108 trips.)
+template <int K, int LQ>
 __global__ __launch_bounds__(256) void knn_small_kernel(const float *__restrict__ q, int nq,
                                                         const float *__restrict__ s, int ns,
                                                         int32_t *__restrict__ idx) {
-    // 8 lanes per query: lane g scans support rows g, g+8, ... into its own sorted list of fp64
-    // (distance,row) keys (see KBest64), then the 8 lists are merged by butterfly exchange.  The key
-    // order is the (distance, row) order, i.e. exactly "strict '<' in row order" of the serial scan.
-    const int g = threadIdx.x & 7;
-    const int i_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int g = threadIdx.x & (LQ - 1);
+    const int i_raw = (blockIdx.x * blockDim.x + threadIdx.x) / LQ;
     const int i = i_raw < nq ? i_raw : nq - 1;            // keep all lanes for the shuffles
     const float qx = q[i * 3], qy = q[i * 3 + 1], qz = q[i * 3 + 2];
     double best[K];
 #pragma unroll
     for (int p = 0; p < K; p++) best[p] = key64(INFINITY, 0x7fffffff);
-    for (int j = g; j < ns; j += 8) {
-        const float dx = qx - s[j * 3], dy = qy - s[j * 3 + 1], dz = qz - s[j * 3 + 2];
-        double t = key64(sqrtf(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)))), j);
-        if (t < best[K - 1]) {
+    for (int j0 = g; j0 < ns; j0 += 4 * LQ) {
+        float sx[4], sy[4], sz[4];
 #pragma unroll
-            for (int p = 0; p < K; p++) {
-                const double lo = fmin(best[p], t);
-                t = fmax(best[p], t);
-                best[p] = lo;
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * LQ < ns ? j0 + u * LQ : ns - 1;
+            sx[u] = s[j * 3];
+            sy[u] = s[j * 3 + 1];
+            sz[u] = s[j * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * LQ;
+            if (j >= ns) break;
+            const float dx = qx - sx[u], dy = qy - sy[u], dz = qz - sz[u];
+            double t = key64(sqrtf(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)))), j);
+            if (t < best[K - 1]) {
+#pragma unroll
+                for (int p = 0; p < K; p++) {
+                    const double lo = fmin(best[p], t);
+                    t = fmax(best[p], t);
+                    best[p] = lo;
+                }
             }
         }
     }
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
+    for (int o = 1; o < LQ; o <<= 1) {
         double other[K];
 #pragma unroll
-        for (int p = 0; p < K; p++) other[p] = __shfl_xor(best[p], o, 8);
+        for (int p = 0; p < K; p++) other[p] = __shfl_xor(best[p], o, LQ);
 #pragma unroll
         for (int e = 0; e < K; e++) {
             double t = other[e];
@@ -720,15 +735,23 @@ OCC_API int occnerf_knn_small(const float *q, int32_t nq, const float *s, int32_
     OCC_REQUIRE(q && s && idx, "knn_small: null argument");
     OCC_REQUIRE(ns >= k, "knn_small: fewer support points (%d) than k (%d)", ns, k);
     if (nq <= 0) return 0;
-    // a few thousand queries at most: 8 lanes per query, 64-thread blocks spread them over the CUs
-    const dim3 grid((nq + 7) / 8), block(64);
+    // a few thousand queries at most: a whole wave per query when the support set is large enough to feed 64 lanes
+    // (one-wave blocks spread over the CUs), 8 lanes per query otherwise
     hipStream_t st = as_stream(stream);
+    const bool wide = ns >= 1024 && nq <= (1 << 20);
+    const dim3 block(64), grid(wide ? nq : (nq + 7) / 8);
+#define OCC_KS(KK)                                                                                      \
+    case KK:                                                                                            \
+        if (wide) hipLaunchKernelGGL((knn_small_kernel<KK, 64>), grid, block, 0, st, q, nq, s, ns, idx); \
+        else hipLaunchKernelGGL((knn_small_kernel<KK, 8>), grid, block, 0, st, q, nq, s, ns, idx);       \
+        break;
     switch (k) {
-        case 1: hipLaunchKernelGGL((knn_small_kernel<1>), grid, block, 0, st, q, nq, s, ns, idx); break;
-        case 3: hipLaunchKernelGGL((knn_small_kernel<3>), grid, block, 0, st, q, nq, s, ns, idx); break;
-        case 10: hipLaunchKernelGGL((knn_small_kernel<10>), grid, block, 0, st, q, nq, s, ns, idx); break;
-        case 16: hipLaunchKernelGGL((knn_small_kernel<16>), grid, block, 0, st, q, nq, s, ns, idx); break;
+        OCC_KS(1)
+        OCC_KS(3)
+        OCC_KS(10)
+        OCC_KS(16)
         default: set_error("knn_small: k=%d not built (1, 3, 10, 16)", k); return 1;
     }
+#undef OCC_KS
     return check_launch("knn_small");
 }

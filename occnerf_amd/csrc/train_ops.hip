@@ -236,13 +236,23 @@ constexpr int kAggMaxK = 40;
 
 __global__ __launch_bounds__(256) void agg_weights_kernel(const float *__restrict__ counter, const int32_t *__restrict__ knn,
                                                           int64_t N, int K, float *__restrict__ atts, float *__restrict__ var_out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    // (round 5) a thread owns a sample, but its K ids / K weights are 4 K bytes apart from its neighbour's: the block's
+    // 256 x K ids come in -- and the weights go out -- coalesced through an LDS tile (row pitch K + 1 words: the 256 rows' reads
+    // spread over the banks).  Same arithmetic, same order.
+    __shared__ uint32_t tile[256 * (kAggMaxK + 1)];
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x;
+    const int rows = N - i0 < (int64_t)blockDim.x ? (int)(N - i0) : (int)blockDim.x;
+    for (int e = threadIdx.x; e < rows * K; e += blockDim.x)
+        tile[(e / K) * (kAggMaxK + 1) + e % K] = (uint32_t)knn[i0 * K + e];
+    __syncthreads();
+    const int64_t i = i0 + threadIdx.x;
+    const bool live = i < N;
+    uint32_t *mine = tile + threadIdx.x * (kAggMaxK + 1);
     float att[kAggMaxK];
     float amin = INFINITY;
 #pragma unroll
     for (int j = 0; j < kAggMaxK; j++) {
-        att[j] = j < K ? counter[knn[i * K + j]] : INFINITY;
+        att[j] = (live && j < K) ? counter[(int32_t)mine[j]] : INFINITY;
         amin = fminf(amin, att[j]);
     }
     float amax = -INFINITY;
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256) void agg_weights_kernel(const float *__restric
             smax = fmaxf(smax, att[j]);
         }
     }
-    var_out[i] = __fdiv_rn(var, (float)(K - 1));
+    if (live) var_out[i] = __fdiv_rn(var, (float)(K - 1));
     float ssum = 0.0f;
 #pragma unroll
     for (int j = 0; j < kAggMaxK; j++) {
@@ -282,7 +292,10 @@ __global__ __launch_bounds__(256) void agg_weights_kernel(const float *__restric
     }
 #pragma unroll
     for (int j = 0; j < kAggMaxK; j++)
-        if (j < K) atts[i * K + j] = __fdiv_rn(att[j], ssum);
+        if (j < K) mine[j] = __float_as_uint(__fdiv_rn(att[j], ssum));      // (own row: read above by this thread only)
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * K; e += blockDim.x)
+        atts[i0 * K + e] = __uint_as_float(tile[(e / K) * (kAggMaxK + 1) + e % K]);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -270,6 +270,7 @@ class Network(nn.Module):
             if cfg.get('dedup_global_positions', False):
                 frows, fcount = ops.unique_heads(xyz, 3, frows, fcount, scan=scan_a, scan_count=count)
         self.last_head_counts = (fcount, None)
+        self._await_center(center)
         if cfg.get('knn_query_list', True):    # tiles formed over the listed samples only (same indices, tested)
             knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], rows=frows, count=fcount, center=center)
         else:
@@ -356,6 +357,12 @@ class Network(nn.Module):
         # (the 4th entry pins what the cached row was computed from: ops.sample_features' freshness contract)
         return center, idx, ops.center_row(row[0], enc_in[0]), self._center_stamp(table)
 
+    @staticmethod
+    def _await_center(center):
+        """The centre tuple may have been produced on the side stream: its last entry is then the event to wait for."""
+        if center is not None and len(center) > 4 and center[4] is not None:
+            torch.cuda.current_stream(center[0].device).wait_event(center[4])
+
     def _center_stamp(self, table):
         return (table.data_ptr(), table._version, self.point_counter._version, self.cnl_mlp.module.encoder.embeddings._version)
 
@@ -421,6 +428,7 @@ class Network(nn.Module):
                 ops.nonrigid_bf16x3(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'], out=xyz)
             else:
                 ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
+        self._await_center(center)
         if cfg.get('knn_culling', True):     # same results, ~5x fewer distance evaluations
             knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], center=center)
         else:
@@ -536,15 +544,33 @@ class Network(nn.Module):
                 wc = self._weight_constants()
                 pack = self._point_pack(wc)
                 f32 = lambda t: t.detach().float().contiguous()          # noqa: E731
+                cond = f32(dst_posevec).reshape(-1) if iter_val >= nr.kick_in_iter else \
+                    torch.zeros(dst_posevec.numel(), device=dev)
+                # The collapse point's chain (its non-rigid offset, its neighbour lists and radius, its feature row: three
+                # single-workgroup kernels, ~0.2 ms of pure latency) is first needed by the kNN stage, milliseconds from now:
+                # it runs on a side stream beside the pose chain, the volume softmax, the bone boxes, the warp and the
+                # non-rigid MLP, and the kNN launch waits for its event (round 5: a rank's fixed per-frame work at N = 8).
+                center = None
+                if cfg.get('knn_center_cache', True) and cfg.get('knn_culling', True):
+                    main = torch.cuda.current_stream(dev)
+                    if cfg.get('center_side_stream', True):
+                        side = self._side_stream(dev)
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            center = self._knn_center(cond, hann.tolist(), wc['table'], pack)
+                            ready = torch.cuda.Event()
+                            ready.record(side)
+                        for t in center[:3]:
+                            t.record_stream(main)
+                        center = center + (ready,)
+                    else:
+                        center = self._knn_center(cond, hann.tolist(), wc['table'], pack)
                 Rs, Ts = ops.pose_motion_bases(self.pose_decoder, f32(dst_posevec).reshape(-1), refine, f32(dst_Rs[0]),
                                                f32(dst_Ts[0]), f32(cnl_gtfms[0]))
                 vol = ops.prior_softmax(wc['dec'], f32(motion_weights_priors[0]))
                 # support box of every bone's weight channel (one tiny launch): the warp kernel skips the bones that cannot
                 # reach a wave's samples -- same bits (cfg.warp_bone_culling=False: every bone for every sample)
                 boxes = ops.bone_boxes(vol, Rs.shape[0]) if cfg.get('warp_bone_culling', True) else None
-                cond = f32(dst_posevec).reshape(-1) if iter_val >= nr.kick_in_iter else \
-                    torch.zeros(dst_posevec.numel(), device=dev)
-                center = self._knn_center(cond, hann.tolist(), wc['table'], pack) if cfg.get('knn_center_cache', True) and cfg.get('knn_culling', True) else None
                 rays_f = f32(torch.stack([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)]) if not torch.is_tensor(rays) else
                              rays.reshape(2, -1, 3))
                 order = morton_order(rays_f[1])

@@ -69,6 +69,11 @@ class PerStepGraph:
             hit = None                                        # a parameter moved (load_state_dict / .to()): capture again
         if hit is None:
             mod = _StaticPart(self.net, refine)
+            # (make_graphed_callables warms up on a side stream, so the parameters' AccumulateGrad nodes belong to that
+            # stream while the step's gradients arrive on the current one: intended here, one event wait per parameter)
+            quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if quiet is not None:
+                quiet(False)
             try:
                 with torch.enable_grad():
                     fn = torch.cuda.make_graphed_callables(mod, tuple(a.clone() for a in args), num_warmup_iters=3,

@@ -1,0 +1,4 @@
+export TMPDIR=/tmp
+python -m pytest tests/test_train_hip.py -x -q 2>&1 | grep -E "^E   |FAILED|passed|failed" | head -12
+python -m pytest tests/test_hip_parity.py -x -q -k "agg or training_step" 2>&1 | tail -2
+python3 tools/train_step_trace.py 20 2>&1 | tail -1

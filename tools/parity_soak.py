@@ -56,6 +56,8 @@ def main():
     ap.add_argument('--spp', type=int, default=64)
     ap.add_argument('--size', type=int, default=64)
     ap.add_argument('--precision', default='fp32')
+    ap.add_argument('--same-preamble', action='store_true',
+                    help="feed the oracle chain the HIP preamble's outputs (Rs, Ts, volume): per-sample kernels alone")
     args = ap.parse_args()
     from oracle import oracle as orc
     orc.build()
@@ -69,9 +71,11 @@ def main():
         R = frame['rays'].shape[1]
         sel = np.sort(rng.choice(R, min(args.rays, R), replace=False))
         frame['rays'], frame['near'], frame['far'] = frame['rays'][:, sel], frame['near'][sel], frame['far'][sel]
+        data = seeded.frame_to_device(frame, 'cuda:0')
         with torch.no_grad():
-            out = net(**seeded.frame_to_device(frame, 'cuda:0'), iter_val=1e7)
-        o = stagewise_oracle_render(None, ctx, frame=frame, S=args.spp, non_rigid=True)
+            out = net(**data, iter_val=1e7)
+        pre = tuple(t.cpu().numpy() for t in net.render_preamble(data)) if args.same_preamble else None
+        o = stagewise_oracle_render(None, ctx, frame=frame, S=args.spp, non_rigid=True, preamble=pre)
         for k in errs:
             e = np.abs(out[k].cpu().numpy() - o[k])
             errs[k].append(e.reshape(len(sel), -1).max(1))
@@ -79,7 +83,7 @@ def main():
         alpha_all.append(o['alpha'])
     frag_all, alpha_all = np.concatenate(frag_all), np.concatenate(alpha_all)
     n = frag_all.size
-    print(f'# Parity soak: HIP ({args.precision}) vs CPU oracle chain, checkpoint recipe {args.level} '
+    print(f'# Parity soak: HIP ({args.precision}) vs CPU oracle chain' + (' fed the HIP preamble outputs' if args.same_preamble else '') + f', checkpoint recipe {args.level} '
           f'({["random-init", "amplified", "trained-like"][args.level]}), {args.frames} frames (seeded poses 100.., random orbit '
           f'cameras, {args.size}x{args.size} image), {n} rays x {args.spp} samples\n')
     print(f'rays with alpha in (0.05, 0.95): {int(((alpha_all > 0.05) & (alpha_all < 0.95)).sum())}; alpha max {alpha_all.max():.3f}; '
