@@ -498,6 +498,13 @@ def main():
     from occnerf_amd.seeded import build_network, host_frame
 
     net = build_network(seed=0, amplify=False, S=SPP, non_rigid=True, device=dev)
+    # experiments only (A/B runs of a renderer option through the whole bench, child processes included):
+    # OCC_BENCH_CFG="key=value,key=value" is applied to the network's cfg and reported in config.cfg_overrides
+    cfg_overrides = {}
+    for kv in filter(None, os.environ.get('OCC_BENCH_CFG', '').split(',')):
+        import yaml
+        k, v = kv.split('=', 1)
+        cfg_overrides[k] = net.cfg[k] = yaml.safe_load(v)
     frame = synth.make_frame(img_size=IMG, pose72=synth.seeded_pose(1), orbit_frame=28)
     frame_h = host_frame(frame)
     R = frame['rays'].shape[1]
@@ -727,6 +734,7 @@ def main():
                        'knn_center_cache': bool(net.cfg.get('knn_center_cache', True)),
                        'warp_bone_culling': bool(net.cfg.get('warp_bone_culling', True)),
                        'world_size_formed': formed_world, 'backend': backend if world > 1 else None,
+                       **({'cfg_overrides': cfg_overrides} if cfg_overrides else {}),
                        'per_rank_rays': [p[0] for p in per_rank],
                        'per_rank_live_samples': [p[1] for p in per_rank],
                        'parallelism': f'one frame, its Morton walk dealt to {world} rank(s) in 256-ray blocks, async RCCL gather '

@@ -29,7 +29,8 @@ static const KnobSpec kKnobSpecs[kKnobCount] = {{"cohab_lds", "OCCNERF_COHAB_LDS
                                                 {"features_rowcache", "OCCNERF_FEATURES_ROWCACHE", 0, 1},
                                                 {"agg_slices", "OCCNERF_AGG_SLICES", 0, 1024},
                                                 {"grid_xcd", "OCCNERF_GRID_XCD", 0, 2},
-                                                {"linear_resident", "OCCNERF_LINEAR_RESIDENT", 0, 2}};
+                                                {"linear_resident", "OCCNERF_LINEAR_RESIDENT", 0, 2},
+                                                {"split_tail", "OCCNERF_SPLIT_TAIL", 0, 2}};
 static std::atomic<int> g_knob[kKnobCount];
 static std::atomic<bool> g_knob_read[kKnobCount];
 

@@ -711,6 +711,65 @@ __global__ __launch_bounds__(256) void grid_grad_runs_kernel(const float *__rest
     }
 }
 
+
+// The same for L*C = 32 floats per row (the encoder of the path: 16 levels x 2 channels), at the speed of a copy.  The
+// general kernel above reads rows[n][j] one float per lane at a 128-byte stride, 32 times: with 32 waves per CU the lines
+// fall out of L1 AND the XCD's L2 between two visits (rocprofv3 --pmc, profiles/r05_train_pmc_hbm.json: 1.06 GB fetched
+// for a 101 MB operand, 0.35 ms).  Here a wave brings its 64 rows in as ONE contiguous 8 KiB piece (16 bytes per lane,
+// 8 loads) into an LDS tile, lane (half, column) walks 32 rows of its column backwards keeping the running sum of the current
+// run -- a head row takes the sum, every other row becomes zero; the run that straddles the two halves hands its lower
+// part's sum to its head in the upper half -- and the tile leaves level by level, 64 rows x 8 bytes = 512 contiguous bytes
+// per store.
+constexpr int kRunPitch = 36;                                      // floats per tile row (16-byte aligned, banks spread)
+__global__ __launch_bounds__(256) void grid_grad_runs32_kernel(const float *__restrict__ rows, const float *__restrict__ inputs,
+                                                               int64_t B, int D, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float tiles[4][64 * kRunPitch];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *tile = tiles[wave];
+    const int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * 64;       // (whole workgroup stays for the barriers)
+    const int64_t n = c0 + lane;
+    const bool live = n < B;
+    bool same = live && lane > 0;
+    for (int d = 0; d < D && same; d++)
+        same = __float_as_uint(inputs[n * D + d]) == __float_as_uint(inputs[(n - 1) * D + d]);
+    const unsigned long long heads = __builtin_amdgcn_ballot_w64(live && !same);
+    // 64 rows x 128 bytes, contiguous in memory: float4 piece i * 64 + lane of the chunk
+    const float4 *src = reinterpret_cast<const float4 *>(rows + c0 * 32);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int piece = i * 64 + lane, r = piece >> 3, q = piece & 7;
+        const float4 v = (c0 + r < B) ? src[piece] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(tile + r * kRunPitch + q * 4) = v;
+    }
+    __syncthreads();
+    const int half = lane >> 5, col = lane & 31;
+    const unsigned hb = half ? (unsigned)(heads >> 32) : (unsigned)heads;
+    float acc = 0.0f;
+    bool fresh = true;                                              // no row of the current run seen yet
+    for (int r = 31; r >= 0; r--) {
+        float *cell = tile + (half * 32 + r) * kRunPitch + col;
+        const float v = *cell;
+        acc = fresh ? v : acc + v;
+        const bool head = (hb >> r) & 1u;
+        *cell = head ? acc : 0.0f;
+        fresh = head;
+    }
+    // the upper half's leftover (rows 32.. of a run whose head sits in the lower half) goes to that head
+    const float carry = __shfl(fresh ? 0.0f : acc, lane + 32);
+    const bool open = !((heads >> 32) & 1ull) && c0 + 32 < B;       // row 32 continues the lower half's last run
+    if (half == 0 && open) {
+        const int p = 31 - __builtin_clz((unsigned)heads);          // (lane 0 always heads a run: never empty)
+        tile[p * kRunPitch + col] += carry;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int l = 0; l < 16; l++)
+            *reinterpret_cast<float2 *>(out + ((int64_t)l * B + n) * 2) =
+                *reinterpret_cast<const float2 *>(tile + lane * kRunPitch + 2 * l);
+    }
+}
+
 }  // namespace occ
 
 /* grad_rows[B][L*C] -> grad[L][B][C] for occnerf_grid_encode_backward, the rows of runs of bitwise identical inputs summed
@@ -723,8 +782,12 @@ OCC_API int occnerf_grid_grad_runs(const float *grad_rows, const float *inputs, 
     OCC_REQUIRE(grad_rows && inputs && grad, "grid_grad_runs: null argument");
     OCC_REQUIRE(D >= 1 && L >= 1 && C >= 1 && (B + 63) / 64 / 4 + 1 < (1ll << 31), "grid_grad_runs: bad size");
     const int64_t waves = (B + 63) / 64;
-    hipLaunchKernelGGL(grid_grad_runs_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), grad_rows, inputs,
-                       B, (int)D, (int)L, (int)C, grad);
+    if (L == 16 && C == 2 && (reinterpret_cast<uintptr_t>(grad_rows) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad) & 7) == 0)
+        hipLaunchKernelGGL(grid_grad_runs32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), grad_rows,
+                           inputs, B, (int)D, grad);
+    else
+        hipLaunchKernelGGL(grid_grad_runs_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), grad_rows,
+                           inputs, B, (int)D, (int)L, (int)C, grad);
     return check_launch("grid_grad_runs");
 }
 

@@ -704,39 +704,48 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
 }
 
 // dW[row_map[n]][col_map[k]] (+)= sum_g part[g][n][k];  db[row_map[n]] (+)= sum_g dbpart[g][n]
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ dbpart, int G, int n_pad,
-                                    int k_pad, const int32_t *__restrict__ row_map, const int32_t *__restrict__ col_map,
-                                    float *__restrict__ dW, int in_dim, float *__restrict__ db, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// A 256-thread workgroup reduces 64 consecutive elements: wave w sums the partial tiles g = w (mod 4) -- a 256-byte row piece
+// per load, eight independent float64 sums in flight -- and wave 0 adds the four waves' sums in a fixed order.  (The first
+// form, one thread per element walking all G tiles, had 4 waves per CU in flight and read its 64 MB at 1.1 TB/s: 60 us per
+// layer, a third of the weight-gradient kernel itself.)  The summation order is fixed by (G, element): deterministic.
+constexpr int kRedElems = 64, kRedSlices = 4;
+__global__ __launch_bounds__(kRedElems * kRedSlices) void wgrad_reduce_kernel(
+    const float *__restrict__ part, const float *__restrict__ dbpart, int G, int n_pad, int k_pad,
+    const int32_t *__restrict__ row_map, const int32_t *__restrict__ col_map, float *__restrict__ dW, int in_dim,
+    float *__restrict__ db, int accumulate) {
+    __shared__ double red[kRedSlices][kRedElems];
+    const int lane = threadIdx.x & (kRedElems - 1), slice = threadIdx.x / kRedElems;
     const int nk = n_pad * k_pad;
-    if (idx < nk) {
+    const int idx = blockIdx.x * kRedElems + lane;            // element of [dW (nk) | db (n_pad)]
+    const bool is_w = idx < nk, is_b = !is_w && db && idx < nk + n_pad;
+    const float *src = is_w ? part + idx : dbpart + (idx - nk);
+    const int64_t pitch = is_w ? nk : n_pad;
+    double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (is_w || is_b) {
+        int g = slice;
+        for (; g + 7 * kRedSlices < G; g += 8 * kRedSlices) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[(int64_t)(g + u * kRedSlices) * pitch];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s8[u] += (double)v[u];
+        }
+        for (; g < G; g += kRedSlices) s8[0] += (double)src[(int64_t)g * pitch];
+    }
+    red[slice][lane] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    __syncthreads();
+    if (slice != 0 || !(is_w || is_b)) return;
+    const double s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (is_w) {
         const int n = idx / k_pad, k = idx - n * k_pad;
         const int rn = row_map[n], ck = col_map[k];
         if (rn >= 0 && ck >= 0) {
-            // eight independent partial sums: the 256 loads of a thread are 256 KiB apart, and with one dependent chain
-            // only a handful were in flight (64 MB in 67 us); same fixed summation order for every element: deterministic
-            double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            int g = 0;
-            for (; g + 8 <= G; g += 8) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = part[(int64_t)(g + u) * nk + idx];
-#pragma unroll
-                for (int u = 0; u < 8; u++) s8[u] += (double)v[u];
-            }
-            for (; g < G; g++) s8[0] += (double)part[(int64_t)g * nk + idx];
-            const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
             float *o = dW + (int64_t)rn * in_dim + ck;
             *o = (float)(accumulate ? (double)*o + s : s);
         }
-    } else if (db && idx < nk + n_pad) {
-        const int n = idx - nk;
-        const int rn = row_map[n];
-        if (rn >= 0) {
-            double s = 0.0;
-            for (int g = 0; g < G; g++) s += (double)dbpart[(int64_t)g * n_pad + n];
-            db[rn] = (float)(accumulate ? (double)db[rn] + s : s);
-        }
+    } else {
+        const int rn = row_map[idx - nk];
+        if (rn >= 0) db[rn] = (float)(accumulate ? (double)db[rn] + s : s);
     }
 }
 
@@ -892,7 +901,8 @@ OCC_API int occnerf_linear_wgrad_reduce(const float *part, const float *dbpart, 
     OCC_REQUIRE(part && dbpart && row_map && col_map && dW, "linear_wgrad_reduce: null argument");
     OCC_REQUIRE(G > 0 && n_pad > 0 && k_pad > 0 && in_dim > 0, "linear_wgrad_reduce: bad sizes");
     const int total = n_pad * k_pad + n_pad;
-    hipLaunchKernelGGL(lin::wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), part, dbpart,
+    hipLaunchKernelGGL(lin::wgrad_reduce_kernel, dim3((total + lin::kRedElems - 1) / lin::kRedElems),
+                       dim3(lin::kRedElems * lin::kRedSlices), 0, as_stream(stream), part, dbpart,
                        G, n_pad, k_pad, row_map, col_map, dW, in_dim, db, accumulate);
     return check_launch("linear_wgrad_reduce");
 }

@@ -547,13 +547,17 @@ class Network(nn.Module):
                 cond = f32(dst_posevec).reshape(-1) if iter_val >= nr.kick_in_iter else \
                     torch.zeros(dst_posevec.numel(), device=dev)
                 # The collapse point's chain (its non-rigid offset, its neighbour lists and radius, its feature row: three
-                # single-workgroup kernels, ~0.2 ms of pure latency) is first needed by the kNN stage, milliseconds from now:
-                # it runs on a side stream beside the pose chain, the volume softmax, the bone boxes, the warp and the
-                # non-rigid MLP, and the kNN launch waits for its event (round 5: a rank's fixed per-frame work at N = 8).
+                # single-workgroup kernels, ~0.2 ms of pure latency) is first needed by the kNN stage, milliseconds from now.
+                # cfg.center_side_stream (OFF by default) runs it on a side stream beside the pose chain, the volume softmax,
+                # the bone boxes, the warp and the non-rigid MLP, the kNN launch waiting for its event.  Measured (round 5,
+                # tools/center_stream_ab.py and bench.py under OCC_BENCH_CFG): a 22 784-ray share takes 20.13 instead of
+                # 20.29 ms in a steady loop, but through bench.py's emulated-rank leg -- a new shard size every few frames --
+                # the slowest of 8 ranks takes 21.4 instead of 20.7 ms (tensors born on the side stream live in that stream's
+                # allocator pool and are released through record_stream: every new size costs fresh device allocations).
                 center = None
                 if cfg.get('knn_center_cache', True) and cfg.get('knn_culling', True):
                     main = torch.cuda.current_stream(dev)
-                    if cfg.get('center_side_stream', True):
+                    if cfg.get('center_side_stream', False):
                         side = self._side_stream(dev)
                         side.wait_stream(main)
                         with torch.cuda.stream(side):

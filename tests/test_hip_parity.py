@@ -1240,8 +1240,8 @@ def test_grid_grad_runs_merge(ops):
     """occnerf_grid_grad_runs (the module backward's transposition [B, L*C] -> [L,B,C] with runs of bitwise identical inputs
     merged) against the plain permutation: (a) with no identical neighbours the output IS the permutation, bit for bit;
     (b) with runs of every length across the 64-sample chunk boundaries -- and -0.0 against +0.0, which are different bit
-    patterns and must not merge -- the embedding gradient of the full backward equals the unmerged one (float64 sum order
-    apart: 2e-6 of the largest entry), and every run's rows sit summed in its first sample with zeros behind."""
+    patterns and must not merge -- the embedding gradient of the full backward equals the unmerged one (B = 20 000 takes the
+    scatter kernel: fp32 global atomics in hardware order, up to 5 000 terms on one cell -- 2e-5 of the largest entry), and every run's rows sit summed in its first sample with zeros behind."""
     from occnerf_amd.gridencoder import grid_offsets
     L, H, D, C = 16, 16, 4, 2
     off, pls = grid_offsets(D, L, 2.0, H, 19, desired_resolution=2048 * 1.4)
@@ -1276,7 +1276,7 @@ def test_grid_grad_runs_merge(ops):
     ga, gb = torch.zeros(total, C, device=DEV), torch.zeros(total, C, device=DEV)
     ops.grid_encode_backward(merged, xt, emb, offsets, ga, B, D, C, L, S_, H)
     ops.grid_encode_backward(perm, xt, emb, offsets, gb, B, D, C, L, S_, H)
-    assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max())
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
     # and through the module: encoder(x).backward(g) takes the merged route for B >= 4096
     from occnerf_amd.gridencoder import GridEncoder
     enc = GridEncoder(input_dim=4, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
@@ -1284,7 +1284,7 @@ def test_grid_grad_runs_merge(ops):
     with torch.no_grad():
         enc.embeddings.uniform_(-1, 1)
     enc(xt, bound=None).backward(gt)
-    assert float((enc.embeddings.grad - gb).abs().max()) <= 2e-6 * float(gb.abs().max())
+    assert float((enc.embeddings.grad - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
 
 
 def test_grid_backward_tiled_vs_scatter(ops):

@@ -606,8 +606,8 @@ def test_fused_pose_chain_and_point_block_match_torch_autograd(amplify):
     train_fused_points off): every output and every parameter gradient of a training forward + backward.  The fused forward
     inverts the bone transforms in closed form where torch runs an LU (1e-7 apart).  Random-init checkpoint: every gradient to
     2e-5 of its largest entry.  Amplified checkpoint (visible pose corrections and point offsets, but O(1) hash features that
-    turn that 1e-7 into 1e-3 of the two gradients behind the table -- tests/test_oracle_golden.py): those two in the L2 sense,
-    the others to 1e-3 (the cotangents the fused kernels receive already differ by that much there)."""
+    turn that 1e-7 into 1e-3 of the gradients at and behind the table -- tests/test_oracle_golden.py): those in the L2 sense,
+    the pose refiner's to 1e-3 (the cotangents the fused kernels receive already differ by that much there)."""
     from occnerf_amd import synth
     frame = synth.make_frame(img_size=32, pose72=synth.seeded_pose(2), orbit_frame=7)
     data = frame_to_device(frame, DEV)
@@ -632,8 +632,9 @@ def test_fused_pose_chain_and_point_block_match_torch_autograd(amplify):
     assert sorted(g_f) == sorted(g_t)
     worst = {}
     for n in g_t:
-        if amplify and n in ('point_dist', 'cnl_mlp.module.pts_linears.0.weight', 'cnl_mlp.module.encoder.embeddings'):
-            worst[n] = float((g_f[n] - g_t[n]).norm() / g_t[n].norm().clamp_min(1e-30)) * 1e-3       # L2, held to 2e-2
+        mine = n.startswith('pose_decoder') or n == 'point_dist'
+        if amplify and not n.startswith('pose_decoder'):
+            worst[n] = float((g_f[n] - g_t[n]).norm() / g_t[n].norm().clamp_min(1e-30))               # L2
         else:
             worst[n] = float((g_f[n] - g_t[n]).abs().max()) / float(g_t[n].abs().max().clamp_min(1e-30))
     focus = {n: f'{v:.1e}' for n, v in worst.items() if n.startswith('pose_decoder') or n == 'point_dist'}
@@ -641,9 +642,15 @@ def test_fused_pose_chain_and_point_block_match_torch_autograd(amplify):
     assert len([n for n in focus if n.startswith('pose_decoder')]) == 10 and 'point_dist' in focus
     for n, v in worst.items():
         # the eleven gradients the fused kernels produce themselves: 2e-5 on the random-init checkpoint (measured 3-8e-6); every
-        # other parameter only sees the 1e-7 difference of the two forwards' bone transforms: 1e-4
+        # other parameter only sees the 1e-7 difference of the two forwards' bone transforms: 1e-4.  Amplified: the pose
+        # refiner's gradients to 1e-3 of their largest entry (measured 1-3e-4), everything at or behind the hash table
+        # (point offsets, table, both trunks) in the L2 sense to 2e-2 -- single entries there move by 1e-3 ... 4e-3 from one
+        # run to the next of the SAME path (fp32 atomics order), the vectors as a whole do not
         mine = n.startswith('pose_decoder') or n == 'point_dist'
-        assert v <= (1e-3 if amplify else (2e-5 if mine else 1e-4)), (n, v)
+        if amplify:
+            assert v <= (1e-3 if n.startswith('pose_decoder') else 2e-2), (n, v)
+        else:
+            assert v <= (2e-5 if mine else 1e-4), (n, v)
 
 
 def test_linear_resident_experiment_matches_shipped_kernel():

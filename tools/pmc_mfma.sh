@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (GPU box, repo root): tools/pmc_mfma.sh <out.json>
+# Usage (GPU box, repo root): tools/pmc_mfma.sh <out.json> [bench legs, default --no-alt; e.g. "--only alt2" adds the f16x3 kernels]
 # MFMA utilisation of the two matrix-pipe kernels of the bench frame (north star: "rocprof ... MFMA utilisation against
 # chip peak").  Three separate --pmc passes, the program directly after `--` (never combined with trace domains):
 #   SQ_INSTS_MFMA, SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_INSTS_VALU | GRBM_GUI_ACTIVE
@@ -7,7 +7,8 @@ out=$1
 export TMPDIR=/tmp
 d=gpurun_out/pmc_mfma
 mkdir -p $d
-args="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt"
+legs=${2:---no-alt}
+args="bench.py --steps 2 --warmup 1 --no-cpu-baseline $legs"
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $d/p1 -o p -- python3 $args > $d/p1.log 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $d/p2 -o p -- python3 $args > $d/p2.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $d/p3 -o p -- python3 $args > $d/p3.log 2>&1
@@ -19,7 +20,8 @@ dur = collections.defaultdict(list)
 for f in glob.glob(f'{d}/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0].replace('void ', '')
-        if k in ('occ::m16::canonical_mlp_lds_kernel', 'occ::nr16::nonrigid_lds_kernel'):
+        if any(t in k for t in ('canonical_mlp_lds_kernel', 'nonrigid_lds_kernel', 'canonical_mlp_split_lds_kernel',
+                                'nonrigid_split_kernel')):
             acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
             if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
                 dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9)
@@ -46,7 +48,9 @@ for k, c in acc.items():
         e['mfma_issue_frac'] = m.get('SQ_INSTS_MFMA', 0) * 32 / (cyc * SIMDS)
         e['launch_ms_profiled'] = t * 1e3
         e['clock_ghz_profiled'] = cyc / t / 1e9
-        e['mfma_tflops_fp32'] = m.get('SQ_INSTS_MFMA', 0) * 2 * 16 * 16 * 4 / t / 1e12
+        # (the split kernels issue v_mfma_f32_32x32x16_{f16,bf16}: 32 768 flops and the same 32 cycles per instruction)
+        per = 2 * 32 * 32 * 16 if 'split' in k else 2 * 16 * 16 * 4
+        e['mfma_tflops_executed'] = m.get('SQ_INSTS_MFMA', 0) * per / t / 1e12
     e['launches'] = len(c.get('SQ_INSTS_MFMA', []))
     res['kernels'][k] = e
 json.dump(res, open(out, 'w'), indent=1)
