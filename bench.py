@@ -172,6 +172,18 @@ TRAIN_PARAM_BYTES = 60.3e6 * 28 + 3 * 62e6 + 134e6      # Adam: p, m, v read + w
 TRAIN_FLOP_PER_ROW = 3 * FLOP_PER_SAMPLE_CNL + FLOP_PER_SAMPLE_NR      # trunks forward + dgrad + wgrad (bf16 MFMA), non-rigid forward (fp32)
 
 
+def train_pmc_traffic():
+    """HBM bytes of one training step from the committed PMC passes (tools/pmc_train.sh; rocprofv3 cannot run inside this
+    process): -> (bytes per step summed over every kernel, file name) or (None, None)."""
+    import glob
+    for name in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_train_hbm_pmc.json'))), reverse=True):
+        try:
+            return float(json.load(open(os.path.join(ROOT, 'profiles', name)))['hbm_bytes_per_step_total']), name
+        except Exception:
+            pass
+    return None, None
+
+
 def train_leg(dev, steps, warmup):
     """BASELINE configs[4]: one optimisation step at the reference's patch configuration (6 x 32 x 32 rays, 128
     samples/ray, jitter on): forward + backward through the HIP sampler / kNN / encoder / MLP / compositor kernels
@@ -216,6 +228,7 @@ def train_leg(dev, steps, warmup):
     t_hbm, t_mfma = nbytes / PEAK_HBM_ACHIEVABLE, flop / PEAK_BF16_MFMA
     from occnerf_amd import train_graph
     pg = train_graph.get(net)
+    traffic, traffic_src = train_pmc_traffic()
     return {'ms_per_step': dt * 1e3, 'rays_per_step': TRAIN_RAYS, 'samples_per_step': rows,
             'rays_per_s': TRAIN_RAYS / dt, 'dtype': 'bf16 MLP trunks (fp32 accumulate, fp32 master weights); '
             'fp32 sampler, encoder, aggregation, compositor', 'final_loss': float(loss.detach()),
@@ -227,6 +240,11 @@ def train_leg(dev, steps, warmup):
                          'algorithmic_bytes_per_step': nbytes, 'bytes_per_row': sum(TRAIN_BYTES_PER_ROW.values()),
                          'achieved': nbytes / dt / 1e9, 'peak': PEAK_HBM_ACHIEVABLE / 1e9, 'unit': 'GB/s',
                          'frac': t_hbm / dt, 'hbm_floor_ms': t_hbm * 1e3,
+                         'traffic': traffic,
+                         'traffic_note': None if traffic is None else
+                         f'NOT measured in this run: HBM bytes of one step summed over every kernel, from the committed file '
+                         f'profiles/{traffic_src} (tools/pmc_train.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over '
+                         f'tools/train_step_trace.py, the guide\'s gfx950 corrections); {traffic / nbytes:.2f}x the algorithmic bytes',
                          'peak_note': '6.3 TB/s = what a streaming kernel achieves on this part (MI355X_MICROARCH.md; datasheet 8 TB/s: '
                                       'frac_of_datasheet below)', 'frac_of_datasheet': nbytes / 8.0e12 / dt,
                          'mfma': {'flop_per_step': flop, 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',

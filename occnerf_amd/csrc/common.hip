@@ -30,7 +30,7 @@ static const KnobSpec kKnobSpecs[kKnobCount] = {{"cohab_lds", "OCCNERF_COHAB_LDS
                                                 {"agg_slices", "OCCNERF_AGG_SLICES", 0, 1024},
                                                 {"grid_xcd", "OCCNERF_GRID_XCD", 0, 2},
                                                 {"linear_resident", "OCCNERF_LINEAR_RESIDENT", 0, 2},
-                                                {"split_tail", "OCCNERF_SPLIT_TAIL", 0, 2}};
+                                                {"split_refill", "OCCNERF_SPLIT_REFILL", 0, 3}};
 static std::atomic<int> g_knob[kKnobCount];
 static std::atomic<bool> g_knob_read[kKnobCount];
 

@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void grid_grad_runs_kernel(const float *__rest
 
 // The same for L*C = 32 floats per row (the encoder of the path: 16 levels x 2 channels), at the speed of a copy.  The
 // general kernel above reads rows[n][j] one float per lane at a 128-byte stride, 32 times: with 32 waves per CU the lines
-// fall out of L1 AND the XCD's L2 between two visits (rocprofv3 --pmc, profiles/r05_train_pmc_hbm.json: 1.06 GB fetched
+// fall out of L1 AND the XCD's L2 between two visits (rocprofv3 --pmc, profiles/r05_train_hbm_pmc.json: 1.06 GB fetched
 // for a 101 MB operand, 0.35 ms).  Here a wave brings its 64 rows in as ONE contiguous 8 KiB piece (16 bytes per lane,
 // 8 loads) into an LDS tile, lane (half, column) walks 32 rows of its column backwards keeping the running sum of the current
 // run -- a head row takes the sum, every other row becomes zero; the run that straddles the two halves hands its lower

@@ -498,7 +498,7 @@ constexpr int kRingSlots = 4;
 constexpr int kChunkUnits = 1024;                                  // 16-byte units per chunk
 constexpr int kChunksTotal = kS_L0Geo + 3 * kS_Hidden + kS_Hidden / 4 + kS_L0Rgb + 3 * kS_Hidden;
 static_assert(BlobH::kTotal == (int64_t)kChunksTotal * kChunkUnits, "bf16 blob is the chunk stream");
-constexpr int kTailChunks = 4;                                     // zero chunks the prefetch may touch (both ring kernels)
+constexpr int kTailChunks = kRingSlots - 1;                        // zero chunks the prefetch may touch
 
 // fp32 side data in LDS (floats): biases in accumulator order + the dot-row weights
 struct Aux {
@@ -538,7 +538,7 @@ __device__ __forceinline__ void lds_bias(f32x16 (&acc)[OB], const float *aux, in
     }
 }
 
-template <typename P>
+template <typename P, bool STAMP = false, bool SPREAD = true>
 __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     const float *__restrict__ mlp_in, const int32_t *__restrict__ in_rows /*nullable: input row of entry n*/, int64_t N_max,
     const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/, const float *__restrict__ pk,
@@ -548,6 +548,13 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     constexpr float kSx = P::kSx, kInvSx = 1.0f / P::kSx;
     const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
     if ((int64_t)blockIdx.x * 128 >= N) return;      // launches are sized for the worst case; uniform per workgroup
+    // STAMP (experiment knob split_refill = 2 / 3, tools/split_kernel_phases.py): s_memtime at the phase boundaries; workgroup 1000's
+    // wave 0 writes the differences over its own output rows (that tile's results are lost: a diagnostic launch)
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, tsplit = 0, tmark = 0;
+#define OCC_STAMP(V) if constexpr (STAMP) V = __builtin_amdgcn_s_memtime();
+#define OCC_SPLIT_BEGIN() if constexpr (STAMP) tmark = __builtin_amdgcn_s_memtime();
+#define OCC_SPLIT_END() if constexpr (STAMP) tsplit += __builtin_amdgcn_s_memtime() - tmark;
+    OCC_STAMP(st0)
     // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read)
     __shared__ __attribute__((aligned(16))) V8 smem[kRingSlots * kChunkUnits + Aux::kTotal / 4];
     V8 *ring = smem;
@@ -585,6 +592,7 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
             bx[s] = split8t<P>(v);
         }
     }
+    OCC_STAMP(st1)
     __syncthreads();
 
     // ---- weight stream: chunk g lives in ring slot g & 3 ----
@@ -610,18 +618,54 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     const V8 *slot_ = ring + (g & (kRingSlots - 1)) * kChunkUnits; \
     g++;
 
+    // SPREAD (the default; experiment knob split_refill = 1 turns it off): the four LDS-DMA pieces of the refill are not issued
+    // right behind the barrier, amid the 16 ds_read_b128 of the k-step (where one piece costs the issuing wave 100-185 cycles:
+    // MI355X_MICROARCH.md), but one by one in the second half of the k-step's MFMAs.  Measured with the STAMP form
+    // (profiles/r05_split_kernel_phases.md): a hidden layer 17.5 K instead of 19.0 K cycles, a tile 147.7 K instead of 153.5 K,
+    // the launch 39.8 instead of 40.3 ms -- two thirds of the cycles saved come back as a lower clock
+    auto issue_piece = [&](int g, int f) {
+        const int frag = wave * 4 + f;
+        glds16(pkh + (size_t)g * kChunkUnits + frag * 64, lane * 16,
+               ring_lds + (unsigned)(((g & (kRingSlots - 1)) * kChunkUnits + frag * 64) * 16));
+    };
+#define OCC_PIECE(F)                                    \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    issue_piece(g + 2, F);                              \
+    __builtin_amdgcn_sched_barrier(0);
+
     // one 16-wide k-step per chunk, 8 output blocks
 #define OCC_LAYER_LDS8(STEPS, ACC, BOPS)                                                   \
     _Pragma("unroll") for (int s_ = 0; s_ < (STEPS); s_++) {                               \
-        OCC_CHUNK_ENTER()                                                                  \
-        V8 ah_[kOB], al_[kOB];                                                             \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ah_[ob_] = slot_[ob_ * 64 + lane];         \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) al_[ob_] = slot_[(kOB + ob_) * 64 + lane]; \
-        const Split &b_ = BOPS(s_);                                                        \
-        const V8 b3_ = P::third(b_.hi);                                                    \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.hi, ACC[ob_]); \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.lo, ACC[ob_]); \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(al_[ob_], b3_, ACC[ob_]);   \
+        if constexpr (!SPREAD) {                                                           \
+            OCC_CHUNK_ENTER()                                                              \
+            V8 ah_[kOB], al_[kOB];                                                         \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ah_[ob_] = slot_[ob_ * 64 + lane];         \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) al_[ob_] = slot_[(kOB + ob_) * 64 + lane]; \
+            const Split &b_ = BOPS(s_);                                                    \
+            const V8 b3_ = P::third(b_.hi);                                                \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.hi, ACC[ob_]); \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.lo, ACC[ob_]); \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(al_[ob_], b3_, ACC[ob_]);   \
+        } else {                                                                           \
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                               \
+            __builtin_amdgcn_s_barrier();                                                  \
+            const V8 *slot_ = ring + (g & (kRingSlots - 1)) * kChunkUnits;                 \
+            g++;                                                                           \
+            V8 ah_[kOB], al_[kOB];                                                         \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ah_[ob_] = slot_[ob_ * 64 + lane];         \
+            const Split &b_ = BOPS(s_);                                                    \
+            const V8 b3_ = P::third(b_.hi);                                                \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.hi, ACC[ob_]); \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) al_[ob_] = slot_[(kOB + ob_) * 64 + lane]; \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.lo, ACC[ob_]); \
+            OCC_PIECE(0)                                                                   \
+            _Pragma("unroll") for (int ob_ = 4; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.lo, ACC[ob_]); \
+            OCC_PIECE(1)                                                                   \
+            _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) ACC[ob_] = P::mfma(al_[ob_], b3_, ACC[ob_]);   \
+            OCC_PIECE(2)                                                                   \
+            _Pragma("unroll") for (int ob_ = 4; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(al_[ob_], b3_, ACC[ob_]); \
+            OCC_PIECE(3)                                                                   \
+        }                                                                                  \
     }
 
     f32x16 acc[kOB];
@@ -631,14 +675,20 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     lds_bias<kOB>(acc, aux + Aux::kGeoL0B, h);
 #define BOPS_X(s) bx[s]
     OCC_LAYER_LDS8(kS_L0Geo, acc, BOPS_X)
+    OCC_SPLIT_BEGIN()
     relu_split(bact, acc);
+    OCC_SPLIT_END()
+    OCC_STAMP(st2)
 #define BOPS_ACT(s) bact[s]
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
         lds_bias<kOB>(acc, aux + Aux::kGeoHB + l * 256, h);
         OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
+        OCC_SPLIT_BEGIN()
         if (l < 2) relu_split(bact, acc);
+        OCC_SPLIT_END()
     }
+    OCC_STAMP(st3)
     float sigma;
     {
         const f32x4 *W4 = reinterpret_cast<const f32x4 *>(aux + Aux::kSigma);
@@ -654,7 +704,10 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         }
         sigma = (sacc + __shfl_xor(sacc, 32)) * kInvSx + aux[Aux::kSigma + 256];
     }
+    OCC_SPLIT_BEGIN()
     relu_split(bact, acc);
+    OCC_SPLIT_END()
+    OCC_STAMP(st4)
     // geometry head: 2 output blocks; a chunk carries 4 k-steps [step][hi|lo][ob][lane]
     f32x16 geo[2];
     lds_bias<2>(geo, aux + Aux::kGeoHeadB, h);
@@ -691,17 +744,24 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         }
     }
 
+    OCC_STAMP(st5)
     // ---------------- colour trunk ----------------
     lds_bias<kOB>(acc, aux + Aux::kRgbL0B, h);
 #define BOPS_RGB0(s) ((s) < 4 ? bgeo[(s) & 3] : bx[((s) - 4) < 0 ? 0 : ((s) - 4)])
     OCC_LAYER_LDS8(kS_L0Rgb, acc, BOPS_RGB0)
+    OCC_SPLIT_BEGIN()
     relu_split(bact, acc);
+    OCC_SPLIT_END()
+    OCC_STAMP(st6)
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
         lds_bias<kOB>(acc, aux + Aux::kRgbHB + l * 256, h);
         OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
+        OCC_SPLIT_BEGIN()
         if (l < 2) relu_split(bact, acc);
+        OCC_SPLIT_END()
     }
+    OCC_STAMP(st7)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the 3 tail chunks: nobody reads them
     float rgb[3];
 #pragma unroll
@@ -726,279 +786,29 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         o[2] = rgb[2];
         o[3] = sigma;
     }
+    if constexpr (STAMP) {
+        st8 = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 1000 && wave == 0 && lane < 10) {
+            const unsigned long long d[10] = {st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4, st6 - st5, st7 - st6,
+                                              st8 - st7, st8 - st0, tsplit};
+            float dv = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 10; i++)
+                if (lane == i) dv = (float)d[i];
+            raw[n * 5] = dv;
+        }
+    }
+#undef OCC_STAMP
+#undef OCC_SPLIT_BEGIN
+#undef OCC_SPLIT_END
 #undef BOPS_X
 #undef BOPS_ACT
 #undef BOPS_RGB0
 #undef OCC_LAYER_LDS8
+#undef OCC_PIECE
 #undef OCC_CHUNK_ENTER
 }
 
-
-// ---------------------------------------------------------------------------------------
-// The same kernel with the layer boundaries pipelined (round 5).  With one wave per SIMD nothing hides a phase that does
-// not feed the matrix pipe, and between two layers the kernel above has one: ReLU + the two-piece split of 128 values per
-// lane (~580 VALU instructions, ~2 600 cycles against the layer's 12 288 MFMA cycles), then 32 LDS reads of the next bias.
-// Here the LAST FOUR k-steps of a layer are taken output-block-major instead of chunk-major: the four chunks are entered
-// together (ring of 8 slots, 4 chunks in flight ahead), a pair of output blocks receives its remaining 24 MFMAs, and while
-// the next pair's 24 run the finished pair is post-processed -- split into the next layer's operands (in place: the tail
-// reads the operands of k-steps 12..15 = blocks 6 and 7, which are split last, after every MFMA has been issued), its
-// accumulators reloaded with the next layer's bias; the sigma / rgb head dots ride the same way.  Same products, same order
-// within an accumulator.
-// ---------------------------------------------------------------------------------------
-constexpr int kTRing = 8;            // ring slots
-constexpr int kTAhead = 4;           // chunks in flight ahead of the one being entered
-constexpr int kTailSteps = 4;        // k-steps of a layer taken output-block-major
-static_assert(kTailChunks >= kTAhead, "the blob's zero tail covers the prefetch");
-
-template <typename P>
-__global__ __launch_bounds__(256, 1) void canonical_mlp_split_tail_kernel(
-    const float *__restrict__ mlp_in, const int32_t *__restrict__ in_rows /*nullable: input row of entry n*/, int64_t N_max,
-    const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/, const float *__restrict__ pk,
-    const typename P::V8 *__restrict__ pkh, float *__restrict__ raw) {
-    typedef typename P::V8 V8;
-    typedef SplitT<P> Split;
-    constexpr float kSx = P::kSx, kInvSx = 1.0f / P::kSx;
-    const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
-    if ((int64_t)blockIdx.x * 128 >= N) return;
-    __shared__ __attribute__((aligned(16))) V8 smem[kTRing * kChunkUnits + Aux::kTotal / 4];
-    static_assert(sizeof(V8) * (kTRing * kChunkUnits + Aux::kTotal / 4) <= 160 * 1024, "LDS budget");
-    V8 *ring = smem;
-    float *aux = reinterpret_cast<float *>(smem + kTRing * kChunkUnits);
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t n = tile * 32 + j;
-    const int64_t nsrc0 = n < N ? n : N - 1;
-    const int64_t nsrc = in_rows ? (int64_t)in_rows[nsrc0] : nsrc0;
-
-    auto copy = [&](int dst, int64_t src, int count, float scale) {
-        for (int i = threadIdx.x; i < count; i += 256) aux[dst + i] = pk[src + i] * scale;
-    };
-    copy(Aux::kGeoL0B, Blob::kGeoL0B, 256, kSx);
-    for (int l = 0; l < 3; l++) copy(Aux::kGeoHB + l * 256, Blob::kGeoHW + l * Blob::kHiddenStride + wsz(kG_Hidden, kOB), 256, kSx);
-    copy(Aux::kGeoHeadB, Blob::kGeoHeadB, 64, kSx);
-    copy(Aux::kSigma, Blob::kSigmaW, 260, 1.0f);
-    copy(Aux::kRgbL0B, Blob::kRgbL0B, 256, kSx);
-    for (int l = 0; l < 3; l++) copy(Aux::kRgbHB + l * 256, Blob::kRgbHW + l * Blob::kHiddenStride + wsz(kG_Hidden, kOB), 256, kSx);
-    copy(Aux::kOut, Blob::kOutW, 772, 1.0f);
-
-    Split bx[kS_L0Geo];
-    {
-        const float *src = mlp_in + nsrc * kInGeo + h * 34;
-#pragma unroll
-        for (int s = 0; s < kS_L0Geo; s++) {
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = (s * 8 + i) < 34 ? P::sym(src[s * 8 + i] * kSx) : 0.0f;
-            bx[s] = split8t<P>(v);
-        }
-    }
-    __syncthreads();
-
-    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) V8 *)ring;
-    auto issue = [&](int g) {
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-            const int frag = wave * 4 + f;
-            glds16(pkh + (size_t)g * kChunkUnits + frag * 64, lane * 16,
-                   ring_lds + (unsigned)(((g & (kTRing - 1)) * kChunkUnits + frag * 64) * 16));
-        }
-    };
-    int g = 0;
-    issue(0);
-    issue(1);
-    issue(2);
-    issue(3);
-
-    // wait for chunk g (chunks g .. g+3 are in flight: 16 pieces of this wave), rendezvous, refill the slot of chunk g-4
-#define OCC_T_ENTER(SLOT)                                              \
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                  \
-    __builtin_amdgcn_s_barrier();                                      \
-    issue(g + kTAhead);                                                \
-    SLOT = ring + (g & (kTRing - 1)) * kChunkUnits;                    \
-    g++;
-
-    // STEPS k-steps into ACC[0..7]: all but the last four chunk-major, the last four by pairs of output blocks with POST(ob)
-    // of the previous pair issued behind the next pair's MFMAs
-#define OCC_T_LAYER(STEPS, ACC, BOPS, POST)                                                                   \
-    {                                                                                                         \
-        constexpr int T_ = (STEPS) < kTailSteps ? (STEPS) : kTailSteps;                                       \
-        _Pragma("unroll") for (int s_ = 0; s_ < (STEPS) - T_; s_++) {                                         \
-            const V8 *slot_;                                                                                  \
-            OCC_T_ENTER(slot_)                                                                                \
-            V8 ah_[kOB], al_[kOB];                                                                            \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ah_[ob_] = slot_[ob_ * 64 + lane];          \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) al_[ob_] = slot_[(kOB + ob_) * 64 + lane];  \
-            const Split &b_ = BOPS(s_);                                                                       \
-            const V8 b3_ = P::third(b_.hi);                                                                   \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.hi, ACC[ob_]); \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.lo, ACC[ob_]); \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(al_[ob_], b3_, ACC[ob_]);   \
-        }                                                                                                     \
-        const V8 *ts_[T_];                                                                                    \
-        _Pragma("unroll") for (int t_ = 0; t_ < T_; t_++) {                                                   \
-            OCC_T_ENTER(ts_[t_])                                                                              \
-        }                                                                                                     \
-        /* 16 units (pair p, step t): 4 fragments, 6 MFMAs; the next unit's fragments are requested first, and */ \
-        /* a quarter of the previous pair's post-processing rides behind the MFMAs */                         \
-        V8 fb_[2][4];                                                                                         \
-        OCC_T_FRAGS(fb_[0], 0, 0)                                                                             \
-        _Pragma("unroll") for (int u_ = 0; u_ < 4 * T_; u_++) {                                               \
-            const int p_ = u_ / T_, t_ = u_ % T_;                                                             \
-            if (u_ + 1 < 4 * T_) {                                                                            \
-                OCC_T_FRAGS(fb_[(u_ + 1) & 1], ((u_ + 1) / T_), ((u_ + 1) % T_))                              \
-            }                                                                                                 \
-            const Split &tb_ = BOPS(((STEPS) - T_ + t_));                                                     \
-            const V8 t3_ = P::third(tb_.hi);                                                                  \
-            ACC[2 * p_] = P::mfma(fb_[u_ & 1][0], tb_.hi, ACC[2 * p_]);                                       \
-            ACC[2 * p_ + 1] = P::mfma(fb_[u_ & 1][1], tb_.hi, ACC[2 * p_ + 1]);                               \
-            ACC[2 * p_] = P::mfma(fb_[u_ & 1][0], tb_.lo, ACC[2 * p_]);                                       \
-            ACC[2 * p_ + 1] = P::mfma(fb_[u_ & 1][1], tb_.lo, ACC[2 * p_ + 1]);                               \
-            ACC[2 * p_] = P::mfma(fb_[u_ & 1][2], t3_, ACC[2 * p_]);                                          \
-            ACC[2 * p_ + 1] = P::mfma(fb_[u_ & 1][3], t3_, ACC[2 * p_ + 1]);                                  \
-            if (p_ > 0) {                                                                                     \
-                POST((2 * p_ - 2 + (t_ >> 1)), (t_ & 1))                                                      \
-            }                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-        }                                                                                                     \
-        POST((kOB - 2), 0)                                                                                    \
-        POST((kOB - 2), 1)                                                                                    \
-        POST((kOB - 1), 0)                                                                                    \
-        POST((kOB - 1), 1)                                                                                    \
-    }
-
-#define OCC_T_FRAGS(DST, PP, TT)                                       \
-    DST[0] = ts_[TT][(2 * (PP)) * 64 + lane];                          \
-    DST[1] = ts_[TT][(2 * (PP) + 1) * 64 + lane];                      \
-    DST[2] = ts_[TT][(kOB + 2 * (PP)) * 64 + lane];                    \
-    DST[3] = ts_[TT][(kOB + 2 * (PP) + 1) * 64 + lane];
-
-    f32x16 acc[kOB];
-    Split bact[2 * kOB];
-    const float *next_bias;          // aux row of the NEXT layer's bias (accumulator order)
-    float sacc = 0.0f, racc[3] = {0.0f, 0.0f, 0.0f};
-
-    // half SUB (8 of the 16 values a lane holds) of output block OB: relu + split into the next layer's operand of k-step
-    // 2 OB + SUB, then those accumulator entries <- the next layer's bias
-#define OCC_T_SPLIT(OB, SUB)                                                                                  \
-    {                                                                                                         \
-        float v_[8];                                                                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) v_[i_] = P::relu(acc[OB][(SUB) * 8 + i_]);           \
-        bact[(OB) * 2 + (SUB)] = split8t<P>(v_);                                                              \
-        const f32x4 *B4_ = reinterpret_cast<const f32x4 *>(next_bias);                                        \
-        _Pragma("unroll") for (int q_ = 2 * (SUB); q_ < 2 * (SUB) + 2; q_++) {                                \
-            const f32x4 bv_ = B4_[((OB) * 4 + q_) * 2 + h];                                                   \
-            _Pragma("unroll") for (int rr_ = 0; rr_ < 4; rr_++) acc[OB][q_ * 4 + rr_] = bv_[rr_];             \
-        }                                                                                                     \
-    }
-    // the same behind the last geometry layer: the sigma row's share of those values from the fp32 values first
-#define OCC_T_SIGMA_SPLIT(OB, SUB)                                                                            \
-    {                                                                                                         \
-        const f32x4 *W4_ = reinterpret_cast<const f32x4 *>(aux + Aux::kSigma);                                \
-        _Pragma("unroll") for (int q_ = 2 * (SUB); q_ < 2 * (SUB) + 2; q_++) {                                \
-            const f32x4 w_ = W4_[((OB) * 4 + q_) * 2 + h];                                                    \
-            _Pragma("unroll") for (int rr_ = 0; rr_ < 4; rr_++)                                               \
-                sacc = __fmaf_rn(w_[rr_], fmaxf(acc[OB][q_ * 4 + rr_], 0.0f), sacc);                          \
-        }                                                                                                     \
-    }                                                                                                         \
-    OCC_T_SPLIT(OB, SUB)
-    // behind the last colour layer: the three output rows' shares of those values
-#define OCC_T_RGB(OB, SUB)                                                                                    \
-    {                                                                                                         \
-        _Pragma("unroll") for (int c_ = 0; c_ < 3; c_++) {                                                    \
-            const f32x4 *W4_ = reinterpret_cast<const f32x4 *>(aux + Aux::kOut + c_ * kWidth);                \
-            _Pragma("unroll") for (int q_ = 2 * (SUB); q_ < 2 * (SUB) + 2; q_++) {                            \
-                const f32x4 w_ = W4_[((OB) * 4 + q_) * 2 + h];                                                \
-                _Pragma("unroll") for (int rr_ = 0; rr_ < 4; rr_++)                                           \
-                    racc[c_] = __fmaf_rn(w_[rr_], fmaxf(acc[OB][q_ * 4 + rr_], 0.0f), racc[c_]);              \
-            }                                                                                                 \
-        }                                                                                                     \
-    }
-
-    // ---------------- geometry trunk ----------------
-    lds_bias<kOB>(acc, aux + Aux::kGeoL0B, h);
-#define BOPS_X(s) bx[s]
-#define BOPS_ACT(s) bact[s]
-    next_bias = aux + Aux::kGeoHB;
-    OCC_T_LAYER(kS_L0Geo, acc, BOPS_X, OCC_T_SPLIT)
-#pragma unroll 1
-    for (int l = 0; l < 2; l++) {
-        next_bias = aux + Aux::kGeoHB + (l + 1) * 256;
-        OCC_T_LAYER(kS_Hidden, acc, BOPS_ACT, OCC_T_SPLIT)
-    }
-    next_bias = aux + Aux::kRgbL0B;                  // (the head below has its own accumulators)
-    OCC_T_LAYER(kS_Hidden, acc, BOPS_ACT, OCC_T_SIGMA_SPLIT)
-    const float sigma = (sacc + __shfl_xor(sacc, 32)) * kInvSx + aux[Aux::kSigma + 256];
-    // geometry head: 2 output blocks; a chunk carries 4 k-steps [step][hi|lo][ob][lane]
-    f32x16 geo[2];
-    lds_bias<2>(geo, aux + Aux::kGeoHeadB, h);
-#pragma unroll
-    for (int c = 0; c < kS_Hidden / 4; c++) {
-        const V8 *slot_;
-        OCC_T_ENTER(slot_)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const Split &b = bact[c * 4 + q];
-            const V8 b3 = P::third(b.hi);
-            V8 ah[2], al[2];
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++) {
-                ah[ob] = slot_[((q * 2 + 0) * 2 + ob) * 64 + lane];
-                al[ob] = slot_[((q * 2 + 1) * 2 + ob) * 64 + lane];
-            }
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++) geo[ob] = P::mfma(ah[ob], b.hi, geo[ob]);
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++) geo[ob] = P::mfma(ah[ob], b.lo, geo[ob]);
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++) geo[ob] = P::mfma(al[ob], b3, geo[ob]);
-        }
-    }
-    Split bgeo[4];
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-#pragma unroll
-        for (int sub = 0; sub < 2; sub++) {
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = P::sym(geo[b][sub * 8 + i]);
-            bgeo[b * 2 + sub] = split8t<P>(v);
-        }
-    }
-
-    // ---------------- colour trunk ----------------  (acc already holds the first layer's bias)
-#define BOPS_RGB0(s) ((s) < 4 ? bgeo[(s) & 3] : bx[((s) - 4) < 0 ? 0 : ((s) - 4)])
-    next_bias = aux + Aux::kRgbHB;
-    OCC_T_LAYER(kS_L0Rgb, acc, BOPS_RGB0, OCC_T_SPLIT)
-#pragma unroll 1
-    for (int l = 0; l < 2; l++) {
-        next_bias = aux + Aux::kRgbHB + (l + 1) * 256;
-        OCC_T_LAYER(kS_Hidden, acc, BOPS_ACT, OCC_T_SPLIT)
-    }
-    OCC_T_LAYER(kS_Hidden, acc, BOPS_ACT, OCC_T_RGB)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero tail chunks: nobody reads them
-    float rgb[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) rgb[c] = (racc[c] + __shfl_xor(racc[c], 32)) * kInvSx + aux[Aux::kOut + 3 * kWidth + c];
-    if (h == 0 && n < N) {
-        float *o = raw + n * 5;
-        o[0] = rgb[0];
-        o[1] = rgb[1];
-        o[2] = rgb[2];
-        o[3] = sigma;
-    }
-#undef BOPS_X
-#undef BOPS_ACT
-#undef BOPS_RGB0
-#undef OCC_T_LAYER
-#undef OCC_T_FRAGS
-#undef OCC_T_ENTER
-#undef OCC_T_SPLIT
-#undef OCC_T_SIGMA_SPLIT
-#undef OCC_T_RGB
-}
 
 }  // namespace occ
 
@@ -1070,11 +880,11 @@ static int mlp_bf16x3_launch(const float *mlp_in, const int32_t *in_rows, int64_
     const int64_t blocks = (N_max + 127) / 128;
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_bf16x3: N too large");
     const bf16x8 *pkh = reinterpret_cast<const bf16x8 *>(packed_bf16);
-    if (variant == 0 && knob(kKnobSplitTail) == 1)
-        hipLaunchKernelGGL(canonical_mlp_split_tail_kernel<Bf16x3>, dim3((unsigned)blocks), dim3(256), 0,
+    if (variant == 0 && knob(kKnobSplitRefill) == 1)
+        hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<Bf16x3, false, false>), dim3((unsigned)blocks), dim3(256), 0,
                            as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
     else if (variant == 0)
-        hipLaunchKernelGGL(canonical_mlp_split_lds_kernel<Bf16x3>, dim3((unsigned)blocks), dim3(256), 0,
+        hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<Bf16x3>), dim3((unsigned)blocks), dim3(256), 0,
                            as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
     else
         hipLaunchKernelGGL(canonical_mlp_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0,
@@ -1100,12 +910,14 @@ OCC_API int occnerf_canonical_mlp_f16x3(const float *mlp_in, const int32_t *in_r
     OCC_REQUIRE(!in_rows || n_dev, "canonical_mlp_f16x3: a row list needs its device-side count");
     const int64_t blocks = (N_max + 127) / 128;
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_f16x3: N too large");
-    if (knob(kKnobSplitTail) == 1)
-        hipLaunchKernelGGL(canonical_mlp_split_tail_kernel<F16x3>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                           mlp_in, in_rows, N_max, n_dev, packed, reinterpret_cast<const f16x8 *>(packed_f16), raw);
-    else
-        hipLaunchKernelGGL(canonical_mlp_split_lds_kernel<F16x3>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                           mlp_in, in_rows, N_max, n_dev, packed, reinterpret_cast<const f16x8 *>(packed_f16), raw);
+    const f16x8 *pkh = reinterpret_cast<const f16x8 *>(packed_f16);
+    const dim3 grid((unsigned)blocks), wg(256);
+    switch (knob(kKnobSplitRefill)) {      // 0: the shipped form; 1: refill pieces at the barrier; 2 / 3: the two with phase stamps
+        case 1: hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3, false, false>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw); break;
+        case 2: hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3, true, true>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw); break;
+        case 3: hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3, true, false>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw); break;
+        default: hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
+    }
     return check_launch("canonical_mlp_f16x3");
 }
 

@@ -288,7 +288,7 @@ __device__ __forceinline__ void nr_glds16(const void *gbase, unsigned lane_off, 
 }
 
 template <typename P>
-__global__ __launch_bounds__(256, 1) void nonrigid_split_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N_max,
+__global__ __launch_bounds__(256, 2) void nonrigid_split_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N_max,
                                                                  const int32_t *__restrict__ rows /*nullable: sample of entry n*/,
                                                                  const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/,
                                                                  const float *__restrict__ pk,

@@ -204,7 +204,7 @@ class _Trunks(Function):
         wgrad(5, dz, 256, GEO, 96, col_map=maps['rgb_seg0'])
         wgrad(5, dz, 256, X0, 96, col_map=maps['rgb_seg1'], with_db=False)
         dgeo = linear_forward(dz, 256, Wt[5][:96], 96, bf16)
-        dx0 = linear_forward(dz, 256, Wt[5][96:], 96, bf16, out_f32=True)
+        dz_rgb0 = dz                                          # (X0's gradient takes both of its consumers at once, below)
         dgeo[:, 64] = draw4[:, 3]
         wgrad(4, dgeo, 96, acts[4], 256)
         dz = linear_forward(dgeo, 96, Wt[4], 256, bf16, mask=acts[4])
@@ -212,7 +212,10 @@ class _Trunks(Function):
             wgrad(l, dz, 256, acts[l], 256)
             dz = linear_forward(dz, 256, Wt[l], 256, bf16, mask=acts[l])
         wgrad(0, dz, 256, X0, 96)
-        dx0 = dx0 + linear_forward(dz, 256, Wt[0], 96, bf16, out_f32=True)
+        # dX0 = dZ(rgb_linears.0) W5[:, X0 part] + dZ(pts_linears.0) W0 as ONE product over K = 256 + 256 (the kernel's two
+        # input segments): two launches + a 75 M-element fp32 add (0.9 GB of traffic, rocprofv3 --pmc) before
+        dx0 = linear_forward(dz_rgb0, 256, torch.cat([Wt[5][96:], Wt[0]], dim=1).contiguous(), 96, bf16, x1=dz, k1=256,
+                             out_f32=True)
         ctx.acts = ctx.GEO = ctx.B = ctx.Wt = None
         return (dx0[:, :35], None, dx0[:, 36:68], None) + tuple(dW) + tuple(db)
 

@@ -713,6 +713,33 @@ def test_canonical_mlp_f16x3_ragged(ops, n):
         assert torch.equal(a[:n - 5], b) and float(a[n - 5:].abs().max()) == 0.0
 
 
+def test_split_refill_forms_bit_identical(ops):
+    """The split kernels issue the four LDS-DMA pieces of a ring refill spread over the k-step's MFMAs (shipped) or right behind
+    the chunk barrier (experiment knob split_refill = 1, the form of the first f16x3 kernel): same products in the same order,
+    so the outputs are bit-identical -- f16x3 and bf16x3, a ragged batch, through a row list too."""
+    from occnerf_amd import _lib
+    ctx = util.model_context(0, False)
+    Wg, Bg, Wc, Bc = util.canonical_mlp_params(ctx['sd'])
+    W = [T(w) for w in Wg + Wc]
+    packed = ops.canonical_mlp_pack(W, [T(b) for b in Bg + Bc])
+    n = 4097
+    x = T((np.random.default_rng(5).standard_normal((n, 68)) * 0.3).astype(np.float32))
+    rows = torch.randperm(n, device=DEV).int()
+    count = torch.tensor([n - 5], device=DEV, dtype=torch.int32)
+    for ph in (ops.canonical_mlp_pack_f16(W), ops.canonical_mlp_pack_bf16(W)):
+        got = []
+        try:
+            for knob in (0, 1):
+                assert _lib.lib().occnerf_experiment_knob(b'split_refill', knob) >= 0
+                a = ops.canonical_mlp_bf16x3(x, packed, ph, torch.zeros(n, 5, device=DEV))
+                b = ops.canonical_mlp_bf16x3(x, packed, ph, torch.zeros(n, 5, device=DEV), count=count, in_rows=rows)
+                got.append((a.clone(), b.clone()))
+        finally:
+            _lib.lib().occnerf_experiment_knob(b'split_refill', 0)
+        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+        assert float(got[0][0][:, :4].abs().max()) > 0
+
+
 def test_canonical_mlp_module_gathered_interface(case, ops):
     """CanonicalMLP.forward with the reference's keyword surface (gathered neighbours)."""
     g, ctx, o = case
@@ -1264,13 +1291,15 @@ def test_grid_grad_runs_merge(ops):
     xt, gt = T(x), T(g)
     merged = ops.grid_grad_runs(gt, xt, B, D, L, C)
     perm = gt.view(B, L, C).permute(1, 0, 2).contiguous()
-    for p0, ln in runs:
-        # inside a 64-sample chunk a run collapses onto its first sample; a run crossing chunk boundaries has one head per chunk
-        bounds = sorted({p0} | {b for b in range((p0 // 64 + 1) * 64, p0 + ln, 64)}) + [p0 + ln]
-        for a, b in zip(bounds[:-1], bounds[1:]):
-            want = perm[:, a:b].double().sum(1)
-            assert float((merged[:, a].double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
-            assert float(merged[:, a + 1:b].abs().max()) == 0.0 if b - a > 1 else True
+    def check_runs(merged, perm):
+        for p0, ln in runs:
+            # inside a 64-sample chunk a run collapses onto its first sample; a run crossing chunk boundaries has one head per chunk
+            bounds = sorted({p0} | {b for b in range((p0 // 64 + 1) * 64, p0 + ln, 64)}) + [p0 + ln]
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                want = perm[:, a:b].double().sum(1)
+                assert float((merged[:, a].double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+                assert float(merged[:, a + 1:b].abs().max()) == 0.0 if b - a > 1 else True
+    check_runs(merged, perm)
     assert torch.equal(merged[:, pos:pos + 2], perm[:, pos:pos + 2])
     emb = torch.zeros(total, C, device=DEV)
     ga, gb = torch.zeros(total, C, device=DEV), torch.zeros(total, C, device=DEV)
@@ -1285,6 +1314,12 @@ def test_grid_grad_runs_merge(ops):
         enc.embeddings.uniform_(-1, 1)
     enc(xt, bound=None).backward(gt)
     assert float((enc.embeddings.grad - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
+    # any other row width takes the general kernel (the 16 x 2 rows above the LDS-tile one): same contract
+    L2, C2 = 5, 3
+    g2 = T(rng.standard_normal((B, L2 * C2)).astype(np.float32))
+    m2, p2 = ops.grid_grad_runs(g2, xt, B, D, L2, C2), g2.view(B, L2, C2).permute(1, 0, 2).contiguous()
+    assert torch.equal(m2[:, :5], p2[:, :5]) and torch.equal(m2[:, pos:], p2[:, pos:])
+    check_runs(m2, p2)
 
 
 def test_grid_backward_tiled_vs_scatter(ops):

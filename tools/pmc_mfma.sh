@@ -20,7 +20,7 @@ dur = collections.defaultdict(list)
 for f in glob.glob(f'{d}/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0].replace('void ', '')
-        if any(t in k for t in ('canonical_mlp_lds_kernel', 'nonrigid_lds_kernel', 'canonical_mlp_split_lds_kernel',
+        if any(t in k for t in ('canonical_mlp_lds_kernel', 'nonrigid_lds_kernel', 'canonical_mlp_split_lds_kernel', 'canonical_mlp_split_tail_kernel',
                                 'nonrigid_split_kernel')):
             acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
             if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
