@@ -43,8 +43,11 @@ const char *occnerf_last_error(void);
  * 0 = automatic, else the sample slices of occnerf_agg_backward), "grid_xcd" (OCCNERF_GRID_XCD: the operator-level D4C2
  * forward with the level pairs dealt to the XCDs -- 0: from 32 768 samples up (the default), 1: always, 2: never;
  * profiles/r05_xcd_levels.md), "linear_resident" (OCCNERF_LINEAR_RESIDENT: 1 / 2 = the weight-resident persistent forms of
- * occnerf_linear_forward with 4 / 8 waves -- both measured slower than the shipped kernel, csrc/linear.hip).  Returns the previous value, -1 for an
- * unknown name.  No counterpart in the reference. */
+ * occnerf_linear_forward with 4 / 8 waves -- both measured slower than the shipped kernel, csrc/linear.hip), "split_refill"
+ * (OCCNERF_SPLIT_REFILL: the split-operand canonical MLP kernels' ring refill -- 0: LDS-DMA pieces spread over the k-step (shipped),
+ * 1: all four behind the chunk barrier (bit-identical, 1.6 % slower), 2 / 3: the two with s_memtime phase stamps written over one
+ * tile's outputs -- diagnostic launches, profiles/r05_split_kernel_phases.md).  Returns the previous value, -1 for an unknown
+ * name.  No counterpart in the reference. */
 int occnerf_experiment_knob(const char *name, int value);
 
 /* ------------------------------------------------------------------------------------

@@ -10,14 +10,13 @@ sys.path.insert(0, os.getcwd())
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from occnerf_amd import _lib, ops  # noqa: E402
-from tests import util  # noqa: E402
+from occnerf_amd.seeded import build_network  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 17_600_000
 dev = torch.device('cuda:0')
-ctx = util.model_context(0, False)
-Wg, Bg, Wc, Bc = util.canonical_mlp_params(ctx['sd'])
-W = [torch.tensor(w, device=dev) for w in Wg + Wc]
-B = [torch.tensor(b, device=dev) for b in Bg + Bc]
+net = build_network(seed=0, amplify=False, S=128, non_rigid=True, device=dev)
+W, B = net.cnl_mlp.module.linear_params()
+W, B = [w.detach() for w in W], [b.detach() for b in B]
 packed = ops.canonical_mlp_pack(W, B)
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn(N, 68, device=dev, generator=g) * 0.3
@@ -67,8 +66,8 @@ for k in (2, 3):
 knob(0)
 del x, raw
 # the non-rigid split kernel (two workgroups per CU since round 5)
-Wn, Bn = util.nonrigid_params(ctx['sd'])
-Wd, Bd = [torch.tensor(w, device=dev) for w in Wn], [torch.tensor(b, device=dev) for b in Bn]
+nr_lin = [m for m in net.non_rigid_mlp.module.block_mlps if isinstance(m, torch.nn.Linear)]
+Wd, Bd = [m.weight.detach() for m in nr_lin], [m.bias.detach() for m in nr_lin]
 pk = ops.nonrigid_pack(Wd, Bd)
 xyz = torch.rand(N, 3, device=dev, generator=g) * 2 - 1
 cond = torch.randn(69, device=dev, generator=g) * 0.3
