@@ -48,6 +48,18 @@ for name, ph in (('f16x3', ops.canonical_mlp_pack_f16(W)), ('bf16x3', ops.canoni
         outs.append(raw)
     print(f'canonical {name}: outputs bit-identical between the forms: {all(torch.equal(outs[0], o) for o in outs[1:])}', flush=True)
     del outs
+# the same instruction stream on all-zero operands (weights, biases and inputs 0): what the clock gives back when the matrix
+# pipe's operands do not toggle -- if the launch gets faster, the sustained clock under load is what bounds the kernel
+knob(0)
+Wz, Bz = [torch.zeros_like(w) for w in W], [torch.zeros_like(b) for b in B]
+pz, phz = ops.canonical_mlp_pack(Wz, Bz), ops.canonical_mlp_pack_f16(Wz)
+raw = torch.zeros(N, 5, device=dev)
+phr = ops.canonical_mlp_pack_f16(W)
+ms_r = timed(lambda: ops.canonical_mlp_bf16x3(x, packed, phr, raw))
+xz = torch.zeros_like(x)
+ms_z = timed(lambda: ops.canonical_mlp_bf16x3(xz, pz, phz, raw))
+print(f'canonical f16x3, random operands {min(ms_r[1:]):.2f} ms; all-zero operands {min(ms_z[1:]):.2f} ms (same kernel, same row count)', flush=True)
+del xz
 ph = ops.canonical_mlp_pack_f16(W)
 names = ['prologue (aux copy, inputs, split)', 'sync + geometry L0 + split', '3 hidden layers (2 splits)', 'sigma dot + split',
          'head + bgeo split', 'colour L0 + split', '3 hidden layers (2 splits)', 'rgb dots + drain + store', 'TOTAL',
