@@ -185,42 +185,54 @@ def train_pmc_traffic():
 
 
 def train_leg(dev, steps, warmup):
-    """BASELINE configs[4]: one optimisation step at the reference's patch configuration (6 x 32 x 32 rays, 128
+    """BASELINE configs[4]: one optimisation step on the reference's patch batch (6 patches of 32 x 32 pixels, 128
     samples/ray, jitter on): forward + backward through the HIP sampler / kNN / encoder / MLP / compositor kernels
     with bf16 MLP trunks, gradient clipping and Adam on the device."""
     from occnerf_amd import synth
     from occnerf_amd.optim import FusedAdam
     from occnerf_amd.seeded import build_network, frame_to_device
-    net = build_network(seed=0, amplify=False, S=SPP, non_rigid=True, device=dev)
-    net.cfg.perturb = 1.0
-    net.cfg.train_precision = 'bf16'
-    net.train()
-    frame = synth.make_frame(img_size=IMG, pose72=synth.seeded_pose(1), orbit_frame=28)
-    R = frame['rays'].shape[1]
-    sel = np.sort(np.random.RandomState(0).choice(R, TRAIN_RAYS, replace=False))
-    for k in ('near', 'far'):
-        frame[k] = frame[k][sel]
-    frame['rays'] = frame['rays'][:, sel]
-    data = frame_to_device(frame, dev)
-    for k in ('cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor'):
-        data[k] = data[k].cpu()
-    opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+    full = synth.make_frame(img_size=IMG, pose72=synth.seeded_pose(1), orbit_frame=28)
+    R = full['rays'].shape[1]
+    from occnerf_amd.seeded import patch_ray_selection
+    # the reference's batch (default.yaml `patch`: N_patches 6, size 32 -- core/data/human_nerf/train.py): 6 random 32 x 32
+    # pixel patches, here required to lie wholly on bbox-hitting pixels so that the batch is 6 144 rays; and, for continuity
+    # with rounds 2-4, the same number of rays scattered over the frame (`scattered_ms_per_step`).  Each batch trains a fresh
+    # copy of the seeded checkpoint (the steps move the field, and with it how many samples collapse).
+    batches = {'patches': patch_ray_selection(full, np.random.RandomState(0), 6, 32, full=True),
+               'scattered': np.sort(np.random.RandomState(0).choice(R, TRAIN_RAYS, replace=False))}
+    timing = {}
+    for name in ('scattered', 'patches'):
+        net = build_network(seed=0, amplify=False, S=SPP, non_rigid=True, device=dev)
+        net.cfg.perturb = 1.0
+        net.cfg.train_precision = 'bf16'
+        net.train()
+        opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+        sel = batches[name]
+        assert sel.size == TRAIN_RAYS
+        frame = dict(full)
+        for k in ('near', 'far'):
+            frame[k] = full[k][sel]
+        frame['rays'] = full['rays'][:, sel]
+        data = frame_to_device(frame, dev)
+        for k in ('cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor'):
+            data[k] = data[k].cpu()
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        out = net(**data, iter_val=1e7)
-        loss = ((out['rgb'] - 0.5) ** 2).mean() + 0.1 * out['comp_loss'].mean()
-        loss.backward()
-        opt.step(max_grad_norm=1.0)
-        return loss
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = net(**data, iter_val=1e7)
+            loss = ((out['rgb'] - 0.5) ** 2).mean() + 0.1 * out['comp_loss'].mean()
+            loss.backward()
+            opt.step(max_grad_norm=1.0)
+            return loss
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        timing[name] = (time.perf_counter() - t0) / steps
+    dt = timing['patches']
     net.cfg.train_precision = 'auto'
     rows = TRAIN_RAYS * SPP
     nbytes = rows * sum(TRAIN_BYTES_PER_ROW.values()) + TRAIN_PARAM_BYTES
@@ -229,7 +241,8 @@ def train_leg(dev, steps, warmup):
     from occnerf_amd import train_graph
     pg = train_graph.get(net)
     traffic, traffic_src = train_pmc_traffic()
-    return {'ms_per_step': dt * 1e3, 'rays_per_step': TRAIN_RAYS, 'samples_per_step': rows,
+    return {'ms_per_step': dt * 1e3, 'batch': '6 random 32 x 32-pixel patches of the 512 x 512 frame (the reference\'s patch sampling)',
+            'scattered_ms_per_step': timing['scattered'] * 1e3, 'rays_per_step': TRAIN_RAYS, 'samples_per_step': rows,
             'rays_per_s': TRAIN_RAYS / dt, 'dtype': 'bf16 MLP trunks (fp32 accumulate, fp32 master weights); '
             'fp32 sampler, encoder, aggregation, compositor', 'final_loss': float(loss.detach()),
             'what': 'forward + backward + clip_grad_norm + Adam, every per-sample stage a HIP kernel '

@@ -42,3 +42,25 @@ def host_frame(frame):
     """The frame as a dataset would hand it over: pinned host tensors; the three float[3] constants stay on the host
     (the kernels take them by value)."""
     return {k: torch.from_numpy(np.ascontiguousarray(frame[k])).pin_memory() for k in FRAME_KEYS}
+
+
+def patch_ray_selection(frame, rng, n_patches=6, size=32, full=False):
+    """Ray indices (into the frame's bbox-hitting ray list) of `n_patches` random size x size pixel patches -- the training
+    batch of the reference (configs/default.yaml:147-150 `patch`, core/data/human_nerf/train.py sample_patch_rays): a patch
+    counts when more than half of its pixels hit the bbox (`full`: all of them, which fixes the batch at n_patches x size^2
+    rays -- the benchmark's 6 x 32 x 32 = 6 144); patches may overlap, as the reference's do."""
+    H = W = int(frame['img_width'])
+    index_of = -np.ones(H * W, dtype=np.int64)
+    index_of[np.nonzero(np.asarray(frame['ray_mask']).reshape(-1))[0]] = np.arange(frame['rays'].shape[1])
+    sel, tries = [], 0
+    while len(sel) < n_patches:
+        tries += 1
+        if tries > 100000:
+            raise RuntimeError('patch_ray_selection: no patch of this size fits the rays of the frame')
+        y, x = rng.randint(0, H - size), rng.randint(0, W - size)
+        pix = (np.arange(y, y + size)[:, None] * W + np.arange(x, x + size)[None, :]).ravel()
+        rays = index_of[pix]
+        if (rays >= 0).all() if full else (rays >= 0).mean() > 0.5:
+            sel.append(rays[rays >= 0])
+    return np.concatenate(sel)
+

@@ -350,3 +350,24 @@ def test_emulated_ranks_cover_the_frame(world):
     assert max(sizes) <= 1.1 * (n / world) + 96
     with pytest.raises(RuntimeError):
         ShardedRenderer(_FakeNet(), 'cpu', emulate=(4, 4))
+
+
+def test_patch_ray_selection_is_the_reference_batch_shape():
+    """The training batch of train.py / bench.py's `train` leg: n_patches random size x size pixel patches (default.yaml `patch`),
+    as indices into the frame's bbox-hitting ray list.  full=True keeps only patches that lie wholly on such pixels, so the batch
+    is exactly n_patches x size^2 rays; every patch is a size x size block of neighbouring pixels."""
+    from occnerf_amd import synth
+    from occnerf_amd.seeded import patch_ray_selection
+    frame = synth.make_frame(img_size=128, pose72=synth.seeded_pose(1), orbit_frame=28)
+    pix_of_ray = np.nonzero(np.asarray(frame['ray_mask']).reshape(-1))[0]
+    sel = patch_ray_selection(frame, np.random.RandomState(3), n_patches=4, size=8, full=True)
+    assert sel.shape == (4 * 64,) and sel.min() >= 0 and sel.max() < frame['rays'].shape[1]
+    for p in range(4):
+        pix = pix_of_ray[sel[p * 64:(p + 1) * 64]]
+        ys, xs = pix // 128, pix % 128
+        assert ys.max() - ys.min() == 7 and xs.max() - xs.min() == 7 and len(np.unique(pix)) == 64
+    loose = patch_ray_selection(frame, np.random.RandomState(3), n_patches=4, size=8, full=False)
+    assert 4 * 32 < loose.size <= 4 * 64
+    again = patch_ray_selection(frame, np.random.RandomState(3), n_patches=4, size=8, full=True)
+    assert np.array_equal(sel, again)
+

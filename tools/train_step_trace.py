@@ -18,7 +18,11 @@ net.cfg.perturb = 1.0
 net.cfg.train_precision = precision
 net.train()
 frame = synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28)
-sel = np.sort(np.random.RandomState(0).choice(frame['rays'].shape[1], 6144, replace=False))
+if os.environ.get('OCC_TRAIN_RAYS', 'patches') == 'patches':      # the reference's batch: 6 patches of 32 x 32 pixels
+    from occnerf_amd.seeded import patch_ray_selection
+    sel = patch_ray_selection(frame, np.random.RandomState(0), 6, 32, full=True)
+else:                                                             # 6 144 rays scattered over the frame (rounds 2-4's batch)
+    sel = np.sort(np.random.RandomState(0).choice(frame['rays'].shape[1], 6144, replace=False))
 for k in ('near', 'far'):
     frame[k] = frame[k][sel]
 frame['rays'] = frame['rays'][:, sel]

@@ -44,17 +44,8 @@ def make_optimizer(net, tc):
 
 def patch_rays(frame, rng, n_patches=6, size=32):
     """6 random 32x32 pixel patches (default.yaml:147-150) restricted to rays that hit the bbox."""
-    H = W = int(frame['img_width'])
-    index_of = -np.ones(H * W, dtype=np.int64)
-    index_of[np.nonzero(frame['ray_mask'])[0]] = np.arange(frame['rays'].shape[1])
-    sel = []
-    while len(sel) < n_patches:
-        y, x = rng.randint(0, H - size), rng.randint(0, W - size)
-        pix = (np.arange(y, y + size)[:, None] * W + np.arange(x, x + size)[None, :]).ravel()
-        rays = index_of[pix]
-        if (rays >= 0).mean() > 0.5:
-            sel.append(rays[rays >= 0])
-    return np.concatenate(sel)
+    from occnerf_amd.seeded import patch_ray_selection
+    return patch_ray_selection(frame, rng, n_patches, size)
 
 
 def main():
