@@ -550,6 +550,16 @@ def test_knn_center_cache_is_exact(ops, oracle):
         outs.append(torch.cat([o['rgb'], o['alpha'][:, None], o['depth'][:, None]], 1))
     net.cfg.knn_center_cache = True
     assert torch.equal(outs[0], outs[1])
+    # the opt-in side-stream placement of the collapse point's chain (cfg.center_side_stream): same kernels, same pixels,
+    # three frames in a row (the second and third meet the first one's tensors in the side stream's allocator pool)
+    net.cfg.center_side_stream = True
+    try:
+        for _ in range(3):
+            with torch.no_grad():
+                o = net(**data, iter_val=1e7)
+            assert torch.equal(torch.cat([o['rgb'], o['alpha'][:, None], o['depth'][:, None]], 1), outs[0])
+    finally:
+        net.cfg.center_side_stream = False
 
 
 def test_point_stage_bit_exact(case, ops, oracle):
