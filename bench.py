@@ -79,6 +79,7 @@ def cpu_baseline(ctx, frame, n_rays):
     from oracle import oracle as orc
     from oracle.chain import stagewise_oracle_render
     orc.build()
+    cores = orc.set_threads(orc.effective_cpus())      # the CPUs this process may use (affinity mask and cgroup quota)
     R = frame['rays'].shape[1]
     sel = np.linspace(0, R - 1, n_rays).astype(np.int64)
     sub = dict(frame)
@@ -88,7 +89,7 @@ def cpu_baseline(ctx, frame, n_rays):
     t0 = time.perf_counter()
     stagewise_oracle_render(None, ctx, frame=sub, S=SPP, non_rigid=True)
     dt = time.perf_counter() - t0
-    return {'value': n_rays / dt, 'unit': 'rays/s', 'cores': os.cpu_count(), 'kind': 'port',
+    return {'value': n_rays / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n_rays} rays x {SPP} samples of the same 512x512 free-view frame, '
                       f'oracle/occnerf_oracle.c (OpenMP), {dt:.1f} s; a literal serial-fmaf port of the reference\'s '
                       'arithmetic (the checker: summation order kept so that indices match bit for bit), NOT a tuned CPU '

@@ -30,24 +30,19 @@ extern "C" {
 
 /* Bumped whenever an existing export's signature or a table layout changes (2: composite/msknn_clustered/
  * sample_features grew arguments in round 2, the Adam table row carries per-tensor bias corrections; 3: msknn_clustered
- * takes the cluster groups; 4: occnerf_agg_backward takes a scratch buffer). */
-#define OCCNERF_ABI_VERSION 4
+ * takes the cluster groups; 4: occnerf_agg_backward takes a scratch buffer; 5: round 6 -- the experiment knobs cohab_lds,
+ * features_small, features_rowcache, linear_resident and split_refill and the kernels behind them left the library). */
+#define OCCNERF_ABI_VERSION 5
 
 int occnerf_abi_version(void);
 const char *occnerf_last_error(void);
 
-/* Experiment knobs: kernel variants that were measured and not shipped stay selectable for A/B runs.  Each knob
- * is read from its environment variable once, at first use, and clamped to its valid range; this call reads (value < 0) or
- * sets it afterwards.  Names: "cohab_lds" (OCCNERF_COHAB_LDS, bytes of padding LDS, 0..131072), "features_small"
- * (OCCNERF_FEATURES_SMALL, 0/1), "features_rowcache" (OCCNERF_FEATURES_ROWCACHE, 0/1), "agg_slices" (OCCNERF_AGG_SLICES,
- * 0 = automatic, else the sample slices of occnerf_agg_backward), "grid_xcd" (OCCNERF_GRID_XCD: the operator-level D4C2
+/* Tuning knobs.  Two remain, both choosing between shipped forms with identical results: "agg_slices" (OCCNERF_AGG_SLICES,
+ * 0 = automatic, else the sample slices of occnerf_agg_backward) and "grid_xcd" (OCCNERF_GRID_XCD: the operator-level D4C2
  * forward with the level pairs dealt to the XCDs -- 0: from 32 768 samples up (the default), 1: always, 2: never;
- * profiles/r05_xcd_levels.md), "linear_resident" (OCCNERF_LINEAR_RESIDENT: 1 / 2 = the weight-resident persistent forms of
- * occnerf_linear_forward with 4 / 8 waves -- both measured slower than the shipped kernel, csrc/linear.hip), "split_refill"
- * (OCCNERF_SPLIT_REFILL: the split-operand canonical MLP kernels' ring refill -- 0: LDS-DMA pieces spread over the k-step (shipped),
- * 1: all four behind the chunk barrier (bit-identical, 1.6 % slower), 2 / 3: the two with s_memtime phase stamps written over one
- * tile's outputs -- diagnostic launches, profiles/r05_split_kernel_phases.md).  Returns the previous value, -1 for an unknown
- * name.  No counterpart in the reference. */
+ * profiles/r05_xcd_levels.md).  Each is read from its environment variable once, at first use, and clamped to its valid range;
+ * this call reads (value < 0) or sets it afterwards.  Returns the previous value, -1 for an unknown name.  No launch in this
+ * library alters its outputs for diagnosis.  No counterpart in the reference. */
 int occnerf_experiment_knob(const char *name, int value);
 
 /* ------------------------------------------------------------------------------------

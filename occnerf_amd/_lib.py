@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCCNERF_HIP_LIB=<path>: load another build of the same library (A/B timing of kernel variants); never a different backend
 LIB_PATH = os.environ.get('OCCNERF_HIP_LIB') or os.path.join(_HERE, 'liboccnerf_hip.so')
 
-ABI_VERSION = 4          # include/occnerf_hip.h OCCNERF_ABI_VERSION this binding mirrors
+ABI_VERSION = 5          # include/occnerf_hip.h OCCNERF_ABI_VERSION this binding mirrors
 
 _vp, _i32, _i64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 

@@ -104,9 +104,6 @@ _DEFAULTS = {
     'knn_culling': True,             # cluster-culled exact kNN (False: brute force)
     'knn_center_cache': True,        # kNN queries within a proven radius of the frame's collapse point take its cached lists (same bits)
     'warp_bone_culling': True,       # warp kernel skips bones whose weight channel cannot reach a wave's samples (same bits)
-    # > 1: the frame's rays in this many chunks, chunk k + 1's sampler / non-rigid / kNN / feature kernels on a second
-    # stream under chunk k's canonical MLP (Network._render_overlapped); bit-identical pixels
-    'overlap_chunks': 0,
 }
 
 _cfg = None

@@ -29,10 +29,11 @@ inline int check_launch(const char *what) {
     return 0;
 }
 
-// Experiment knobs (A/B variants that were measured and NOT shipped).  Each is read from its environment
-// variable ONCE (first use), validated and clamped there, and can be switched at run time through the exported
-// occnerf_experiment_knob() -- launches never call getenv / atoi.
-enum Knob : int { kKnobCohabLds = 0, kKnobFeaturesSmall = 1, kKnobFeaturesRowcache = 2, kKnobAggSlices = 3, kKnobGridXcd = 4, kKnobLinearResident = 5, kKnobSplitRefill = 6, kKnobCount = 7 };
+// Tuning knobs (round 6: the two that select between shipped, bit-identical forms; the experiment variants of earlier
+// rounds are gone from the library -- HISTORY.md keeps their numbers).  Each is read from its environment variable ONCE (first
+// use), validated and clamped there, and can be switched at run time through the exported occnerf_experiment_knob() --
+// launches never call getenv / atoi.
+enum Knob : int { kKnobAggSlices = 0, kKnobGridXcd = 1, kKnobCount = 2 };
 int knob(Knob k);
 
 #define OCC_REQUIRE(cond, ...)         \

@@ -22,15 +22,8 @@ struct KnobSpec {
     const char *name, *env;
     int lo, hi;
 };
-// cohab_lds: bytes of unused dynamic LDS that pad a kNN / feature workgroup (the co-residency experiment of round 4);
-// at most what a gfx950 workgroup can still ask for beside those kernels' static LDS.
-static const KnobSpec kKnobSpecs[kKnobCount] = {{"cohab_lds", "OCCNERF_COHAB_LDS", 0, 128 * 1024},
-                                                {"features_small", "OCCNERF_FEATURES_SMALL", 0, 1},
-                                                {"features_rowcache", "OCCNERF_FEATURES_ROWCACHE", 0, 1},
-                                                {"agg_slices", "OCCNERF_AGG_SLICES", 0, 1024},
-                                                {"grid_xcd", "OCCNERF_GRID_XCD", 0, 2},
-                                                {"linear_resident", "OCCNERF_LINEAR_RESIDENT", 0, 2},
-                                                {"split_refill", "OCCNERF_SPLIT_REFILL", 0, 3}};
+static const KnobSpec kKnobSpecs[kKnobCount] = {{"agg_slices", "OCCNERF_AGG_SLICES", 0, 1024},
+                                                {"grid_xcd", "OCCNERF_GRID_XCD", 0, 2}};
 static std::atomic<int> g_knob[kKnobCount];
 static std::atomic<bool> g_knob_read[kKnobCount];
 

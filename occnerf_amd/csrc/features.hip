@@ -779,368 +779,6 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// sample_features8r_kernel: the 8-lanes-per-sample kernel with a per-wave ROW CACHE.
-//
-// The 8 samples of a wave trip are consecutive listed samples of a ray, ~1 cm apart: of the 8 x 40 per-point table rows
-// they gather only 45 are distinct on the benchmark frame (tools/row_sharing.py: 14 %; p99 144), and those 320 x 128 B
-// went through the 64 B/clk L1 data path one row per gather instruction -- 46 % of the kernel's time.  Here every
-// distinct row enters LDS once per trip and the samples read their 40 rows from there (LDS has its own 128 B/clk path):
-//   * dedup without sorting: a 4 x 128-bucket table per wave; every lane writes (id, own code) for its five ids into the
-//     bucket id & 127 of its scale, reads the bucket back, and is the id's LEADER if it finds its own code there or
-//     another id (a lost bucket: it then leads alone -- a duplicate fetch, still correct); followers learn their leader's
-//     code.  Slots are the leaders' ranks in code order, which every lane can compute for ANY code from the five
-//     wave-uniform ballot masks -- no second pass through LDS;
-//   * the leaders' rows (128 B of encoding + the 16-byte tail piece) are brought in by LDS-DMA (global_load_lds_dwordx4:
-//     lane p of the stream fetches piece p % 9 of slot p / 9), issued first thing in the trip so that the geometry and
-//     hash phases cover their latency;
-//   * rows beyond kRowCap distinct ones per trip are gathered from L2 as before (same values).
-// The (tail, count) image of all points in LDS shrinks to the counts (the tails arrive with the rows).  Arithmetic and
-// summation order are those of sample_features8_kernel: bit-identical outputs (tested against it on the benchmark frame).
-//
-// MEASURED (round 3, benchmark frame, 17.6 M rows; profiles/archive/r03_features_rowcache.md): bit-identical and SLOWER,
-// 12.6 ms against 10.0 ms, so it is OPT-IN (OCCNERF_FEATURES_ROWCACHE=1) and the renderer keeps sample_features8_kernel.
-// Gather instructions per trip fall 83 -> 71 only (one trip in five has more than 56 distinct rows and falls back), the
-// texture path stays as busy (TA busy 1.80e7 vs 1.74e7 cycles per XCD: LDS-DMA pieces pay the texture path too, and land
-// at a fraction of the L1 rate), LDS instructions rise 188 -> 282 per trip, and the waves now sit parked on s_waitcnt half of
-// their time (SQ_WAIT_ANY 18 % -> 50 %): with three waves per SIMD the kernel is bound by the length of a trip's chain of
-// dependent round trips, and the election (bucket write -> read -> slot publish -> read -> id list -> DMA) adds five LDS
-// round trips to the head of it.  Staging through registers instead of LDS-DMA: 18.7 ms.  Without the election and the DMA
-// (wrong results, timing only) the LDS-fed row phase runs the kernel at 8.5 ms -- the ceiling of this direction.
-// ---------------------------------------------------------------------------------------
-constexpr int kRowCap = 56;               // rows staged per wave trip
-constexpr int kRowPieces = 9;             // 16-byte pieces per staged row: columns 0..35 of the table row
-constexpr int kCountPoints = 8192;        // counts of all points in LDS (32 KiB)
-constexpr int kRowWaves = 12;             // waves per workgroup (one workgroup per CU)
-
-struct __attribute__((aligned(16))) WaveRows {
-    float4 stage[kRowCap * kRowPieces];   // 8 064 B
-    uint32_t bucket[4 * 128];             // 2 048 B: (id << 16 | code) per (scale, id & 127)
-    uint16_t code_slot[5 * 64];           //   640 B: slot of the leader with code (round << 6 | lane)
-    uint16_t slot_id[64];                 //   128 B: point id of the row staged in slot s
-};
-static_assert(sizeof(WaveRows) == 10880 && 32768 + 12 * sizeof(WaveRows) <= 163840, "LDS budget: 32 KiB of counts + 12 waves");
-
-template <bool GENERIC>
-__global__ __launch_bounds__(kRowWaves * 64, 3) void sample_features8r_kernel(
-    const float *__restrict__ xyz, int64_t N_max, const int32_t *__restrict__ knn_idxs,
-    const float4 *__restrict__ geo, const float4 *__restrict__ tailc, const float4 *__restrict__ table,
-    const float2 *__restrict__ embeddings, LevelRecs levels, LevelRecs8 levels8, FeatParams prm,
-    const int32_t *__restrict__ rows, const int32_t *__restrict__ n_dev, float *__restrict__ mlp_in, float *__restrict__ raw,
-    float *__restrict__ enc_in_out) {
-    constexpr int NK = 4 * kKnn;
-    __shared__ float s_count[kCountPoints];
-    __shared__ WaveRows s_rows[kRowWaves];
-    for (int i = threadIdx.x; i < prm.P; i += blockDim.x) s_count[i] = tailc[i].w;
-    __syncthreads();
-    const int g = threadIdx.x & 7;
-    const int lane64 = threadIdx.x & 63;
-    const int tr = ((lane64 & 7) << 3) | (lane64 >> 3);
-    WaveRows &wr = s_rows[threadIdx.x >> 6];
-    uint32_t *const bk = wr.bucket + (g >> 1) * 128;               // this lane's ids belong to scale g >> 1
-    const unsigned stage_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float4 *)wr.stage;
-    const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
-    if (N <= 0) return;
-    const int64_t group0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> 3;
-    const int64_t iters = (N + ngroups - 1) / ngroups;
-
-    struct StageA {
-        float p[3];
-        int idg, id89;
-        int id5[5];
-    };
-    auto out_row = [&](int64_t it) {
-        const int64_t i_raw = group0 + it * ngroups;
-        return i_raw < N ? i_raw : N - 1;
-    };
-    auto load_a = [&](int64_t i, StageA &a) {
-        const int32_t *id = knn_idxs + i * NK;
-        struct __attribute__((packed, aligned(4))) F3 { float v[3]; };
-        struct __attribute__((packed, aligned(4))) I4 { int v[4]; };
-        const F3 pq = *reinterpret_cast<const F3 *>(xyz + i * 3);
-        a.p[0] = pq.v[0], a.p[1] = pq.v[1], a.p[2] = pq.v[2];
-        a.idg = id[g];
-        a.id89 = id[8 + (g >> 2)];
-        const I4 q = *reinterpret_cast<const I4 *>(id + g * 5);
-        a.id5[0] = q.v[0], a.id5[1] = q.v[1], a.id5[2] = q.v[2], a.id5[3] = q.v[3];
-        a.id5[4] = id[g * 5 + 4];
-    };
-    StageA cur, nxt;
-    int32_t i1;
-    {
-        const int64_t o0 = out_row(0), o1 = out_row(1);
-        load_a(rows ? (int64_t)rows[o0] : o0, cur);
-        i1 = rows ? rows[o1] : (int32_t)o1;
-    }
-    for (int64_t it = 0; it < iters; it++) {
-        const bool live = group0 + it * ngroups < N;
-        const int64_t o = out_row(it);
-        const int64_t o2 = out_row(it + 2);
-        float *out = mlp_in + o * 68;
-
-        load_a(i1, nxt);
-        const int32_t i2 = rows ? rows[o2] : (int32_t)o2;
-        // ---- distinct rows of the trip: leaders, slots, LDS-DMA of the leaders' rows ----
-        uint32_t code[5];                                  // code of the lane that leads this id: round << 6 | lane
-#pragma unroll
-        for (int k = 0; k < 5; k++) bk[cur.id5[k] & 127] = ((uint32_t)cur.id5[k] << 16) | (uint32_t)(k << 6 | lane64);
-        // leaders take consecutive slots in (round, lane) order -- ballot + mbcnt -- and publish them under their code;
-        // every lane then picks up the slot of the code that leads its id (one LDS write + read per round, no cross-lane math)
-        uint32_t nslots = 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const uint32_t v = bk[cur.id5[k] & 127], mine = (uint32_t)(k << 6 | lane64);
-            const bool leader = (v >> 16) != (uint32_t)cur.id5[k] || (v & 0x1ffu) == mine;
-            code[k] = leader ? mine : (v & 0x1ffu);
-            const unsigned long long lead = __builtin_amdgcn_ballot_w64(leader);
-            const uint32_t own = nslots + __builtin_amdgcn_mbcnt_hi((uint32_t)(lead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lead, 0u));
-            if (leader) {
-                wr.code_slot[mine] = (uint16_t)own;
-                if (own < (uint32_t)kRowCap) wr.slot_id[own] = (uint16_t)cur.id5[k];
-            }
-            nslots += (uint32_t)__builtin_popcountll(lead);
-        }
-        uint32_t slot[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) slot[k] = wr.code_slot[code[k]];
-        const bool overflow = nslots > (uint32_t)kRowCap;  // wave-uniform
-        const uint32_t pieces = (overflow ? (uint32_t)kRowCap : nslots) * kRowPieces;
-        {
-            for (uint32_t p0 = 0; p0 < pieces; p0 += 64) {
-                const uint32_t pp = p0 + (uint32_t)lane64;
-                if (pp < pieces) {
-                    const uint32_t sl = (pp * 0xE38Fu) >> 19;             // pp / 9 for pp < 504
-                    const uint32_t voff = (uint32_t)wr.slot_id[sl] * (uint32_t)(kTableStride * 4) + (pp - sl * kRowPieces) * 16u;
-                    unsigned keep;
-                    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(stage_lds + p0 * 16u));   // wave-uniform
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                                 "s_mov_b32 m0, %0"
-                                 : "=&s"(keep)
-                                 : "v"(voff), "s"(table), "s"(dst)
-                                 : "memory");
-                }
-            }
-        }
-
-        // visibility counts of the lane's five rows
-        float cnt5[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) cnt5[k] = s_count[cur.id5[k]];
-
-        // ---- neighbour geometry (as sample_features8_kernel) ----
-        float nrm[5];
-        int negf[5];
-        double t_att[2] = {0.0, 0.0}, t_num[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-        {
-            float4 pc[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int nid = k < 4 ? __shfl(cur.idg, 2 * k + (g >> 2), 8) : cur.id89;
-                pc[k] = ld32(geo, (uint32_t)nid * 64u + (uint32_t)(g & 3) * 16u);
-            }
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const float nbr[3] = {quad_bcast<0>(pc[k].x), quad_bcast<0>(pc[k].y), quad_bcast<0>(pc[k].z)};
-                const double nx = quad_bcast_f64<1>(pc[k].x, pc[k].y), ny = quad_bcast_f64<1>(pc[k].z, pc[k].w);
-                const double nz = quad_bcast_f64<2>(pc[k].x, pc[k].y);
-                float dir[3];
-#pragma unroll
-                for (int c = 0; c < 3; c++) dir[c] = __fsub_rn(cur.p[c], nbr[c]);
-                double dot = __dadd_rn(0.0, __dmul_rn((double)dir[0], nx));
-                dot = __dadd_rn(dot, __dmul_rn((double)dir[1], ny));
-                dot = __dadd_rn(dot, __dmul_rn((double)dir[2], nz));
-                negf[k] = dot < 0.0;
-                nrm[k] = norm3(dir[0], dir[1], dir[2]);
-                if (k < 2) {
-                    const double un[3] = {quad_bcast_f64<2>(pc[k].z, pc[k].w), quad_bcast_f64<3>(pc[k].x, pc[k].y),
-                                          quad_bcast_f64<3>(pc[k].z, pc[k].w)};
-                    t_att[k] = fabs(cos3_unit(dir, un));
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const float pn = __fdiv_rn(__fadd_rn(nbr[c], prm.bound), prm.two_bound);
-                        t_num[k][c] = __dmul_rn(t_att[k], (double)pn);
-                    }
-                }
-            }
-        }
-        float dsum = 0.0f;
-        int neg = 0;
-#pragma unroll
-        for (int j = 0; j < kKnn; j++) {
-            dsum = __fadd_rn(dsum, __shfl(nrm[j >> 1], 4 * (j & 1), 8));
-            neg += __shfl(negf[j >> 1], 4 * (j & 1), 8);
-        }
-        double num[3] = {0.0, 0.0, 0.0}, den = 0.0;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) num[c] = __dadd_rn(num[c], __shfl(t_num[j >> 1][c], 4 * (j & 1), 8));
-            den = __dadd_rn(den, __shfl(t_att[j >> 1], 4 * (j & 1), 8));
-        }
-        float dist = __fdiv_rn(dsum, (float)kKnn);
-        if (2 * neg > kKnn) dist = -dist;
-        float nd = __fdiv_rn(__fadd_rn(dist, 0.2f), 0.5f);
-        nd = nd < 0.0f ? 0.0f : (nd > 1.0f ? 1.0f : nd);
-        float x[4];
-#pragma unroll
-        for (int c = 0; c < 3; c++) x[c] = (float)__ddiv_rn(num[c], den);
-        x[3] = nd;
-        if (live && g == 0) {
-            raw[o * 5 + 4] = dist;
-            if (enc_in_out) *reinterpret_cast<float4 *>(enc_in_out + o * 4) = make_float4(x[0], x[1], x[2], x[3]);
-        }
-
-        // ---- visibility softmax: lane g owns neighbours 5g..5g+4 ----
-        float a5[5];
-        float lmin = INFINITY;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            a5[k] = cnt5[k];
-            lmin = fminf(lmin, a5[k]);
-        }
-        const float amin = grp_min8(lmin);
-        float lmax = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            a5[k] = __fadd_rn(a5[k], __fsub_rn(1.0f, amin));
-            lmax = fmaxf(lmax, a5[k]);
-        }
-        const float amax = grp_max8(lmax);
-        float lsum = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            a5[k] = __fdiv_rn(a5[k], amax);
-            lsum += a5[k];
-        }
-        const float mean = __fdiv_rn(grp_sum8(lsum), (float)NK);
-        float lvar = 0.0f, lsm = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const float dl = a5[k] - mean;
-            lvar += dl * dl;
-            lsm = fmaxf(lsm, a5[k]);
-        }
-        const float var = __fdiv_rn(grp_sum8(lvar), (float)(NK - 1));
-        const float smax = grp_max8(lsm);
-        float le = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            a5[k] = expf(__fsub_rn(a5[k], smax));
-            le += a5[k];
-        }
-        const float ssum = grp_sum8(le);
-#pragma unroll
-        for (int k = 0; k < 5; k++) a5[k] = __fdiv_rn(a5[k], ssum);
-
-        // ---- hash encoding (as sample_features8_kernel) ----
-        float xt[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) xt[d] = __shfl(x[d], tr);
-        bool oob = false;
-#pragma unroll
-        for (int d = 0; d < 4; d++) oob |= (xt[d] < 0.f || xt[d] > 1.f);
-        __builtin_amdgcn_sched_barrier(0);
-        LevelTaps4 tp[2];
-        if (oob) {
-#pragma unroll
-            for (int d = 0; d < 4; d++) xt[d] = 0.5f;
-        }
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            if constexpr (GENERIC) {
-                const LevelRec4 lr = levels.r[2 * (lane64 >> 3) + a];
-                encode_level_d4c2_taps(xt, embeddings, lr.size, lr.scale, lr.res_mode & 0xFFFFFFu, lr.res_mode >> 24,
-                                       lr.entry0, tp[a]);
-            } else {
-                level_taps_select(xt, embeddings, levels8.r[2 * (lane64 >> 3) + a], tp[a]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        float2 evt[2];
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            evt[a] = encode_level_d4c2_reduce(tp[a]);
-            if (oob) evt[a] = make_float2(0.f, 0.f);
-        }
-        // ---- the staged rows have landed (every load of this trip has: the corners were just consumed).  The wait sits
-        // BEFORE this trip's stores: vmcnt counts stores too, and a store's acknowledgement takes a microsecond ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float2 ev[2];
-#pragma unroll
-        for (int a = 0; a < 2; a++) ev[a] = make_float2(__shfl(evt[a].x, tr), __shfl(evt[a].y, tr));
-        if (live) *reinterpret_cast<float4 *>(out + 36 + 4 * g) = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);
-
-        // tails of the lane's five rows, then the 40 rows in neighbour order
-        float tail[3] = {0.f, 0.f, 0.f};
-        float agg[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!overflow) {
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const float4 tl = wr.stage[slot[k] * kRowPieces + 8];
-                tail[0] += a5[k] * tl.x;
-                tail[1] += a5[k] * tl.y;
-                tail[2] += a5[k] * tl.z;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        const float w = __shfl(a5[k], 2 * c + h, 8);
-                        const float4 t = wr.stage[__shfl(slot[k], 2 * c + h, 8) * kRowPieces + g];
-                        agg[0] = __fadd_rn(agg[0], __fmul_rn(w, t.x));
-                        agg[1] = __fadd_rn(agg[1], __fmul_rn(w, t.y));
-                        agg[2] = __fadd_rn(agg[2], __fmul_rn(w, t.z));
-                        agg[3] = __fadd_rn(agg[3], __fmul_rn(w, t.w));
-                    }
-                }
-            }
-        } else {                                            // more distinct rows than slots: the others come from L2
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                float4 tl;
-                if (slot[k] < (uint32_t)kRowCap) tl = wr.stage[slot[k] * kRowPieces + 8];
-                else tl = ld32(tailc, (uint32_t)cur.id5[k] * 16u);
-                tail[0] += a5[k] * tl.x;
-                tail[1] += a5[k] * tl.y;
-                tail[2] += a5[k] * tl.z;
-            }
-#pragma unroll 1
-            for (int c = 0; c < 4; c++) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        const float w = __shfl(a5[k], 2 * c + h, 8);
-                        const uint32_t sl = __shfl(slot[k], 2 * c + h, 8);
-                        const uint32_t id = (uint32_t)__shfl(cur.id5[k], 2 * c + h, 8);
-                        float4 t;
-                        if (sl < (uint32_t)kRowCap) t = wr.stage[sl * kRowPieces + g];
-                        else t = ld32(table, id * (uint32_t)(kTableStride * 4) + (uint32_t)g * 16u);
-                        agg[0] = __fadd_rn(agg[0], __fmul_rn(w, t.x));
-                        agg[1] = __fadd_rn(agg[1], __fmul_rn(w, t.y));
-                        agg[2] = __fadd_rn(agg[2], __fmul_rn(w, t.z));
-                        agg[3] = __fadd_rn(agg[3], __fmul_rn(w, t.w));
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) tail[c] = grp_sum8(tail[c]);
-        if (live) {
-            *reinterpret_cast<float4 *>(out + 4 * g) = make_float4(agg[0], agg[1], agg[2], agg[3]);
-            if (g == 0) *reinterpret_cast<float4 *>(out + 32) = make_float4(tail[0], tail[1], tail[2], var);
-        }
-        // the stage and the buckets are rewritten at the top of the next trip: every LDS read of this trip must have
-        // returned (same wave, in-order LDS pipe; the wait keeps the compiler from sinking reads below the DMA issue)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        cur = nxt;
-        i1 = i2;
-    }
-}
 
 }  // namespace occ
 
@@ -1271,32 +909,14 @@ OCC_API int occnerf_sample_features_centered(const float *xyz, int64_t N, const 
                                      dense ? r1 * r1 * r1 : 3674653429u, 0u};
         }
         OCC_REQUIRE(P > 0, "sample_features: P=%d rows of packed point records", P);
-        const bool force_small = knob(kKnobFeaturesSmall) != 0;      // experiment: 4-wave workgroups, counts from L2
-        const bool lds_tail = P <= kLdsTailPoints && N >= 96 * 64 && !force_small;      // (small calls: not worth a block-wide LDS image -- kLdsTailPoints x 16 B of (tail, count) records + 12 KiB of encoding slots, 156 of 160 KiB)
+        const bool lds_tail = P <= kLdsTailPoints && N >= 96 * 64;      // (small calls: not worth a block-wide LDS image -- kLdsTailPoints x 16 B of (tail, count) records + 12 KiB of encoding slots, 156 of 160 KiB)
         const int threads = lds_tail ? 768 : 256;
         int64_t blocks8 = (N * 8 + threads - 1) / threads;
         const int64_t cap = lds_tail ? (int64_t)kNumCU : (int64_t)kNumCU * 32;
         if (blocks8 > cap) blocks8 = cap;
-        // row cache (sample_features8r_kernel): opt-in with OCCNERF_FEATURES_ROWCACHE=1 -- bit-identical, measured slower
-        // (see the kernel's header)
-        const bool rowcache_on = knob(kKnobFeaturesRowcache) != 0;
-        if (lds_tail && rowcache_on && P <= kCountPoints) {
-            auto kr = generic ? sample_features8r_kernel<true> : sample_features8r_kernel<false>;
-            hipLaunchKernelGGL(kr, dim3((unsigned)blocks8), dim3(kRowWaves * 64), 0, as_stream(stream), xyz, N, knn_idxs,
-                               reinterpret_cast<const float4 *>(point_geo), reinterpret_cast<const float4 *>(point_tail),
-                               reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings), levels,
-                               levels8, prm, rows, n_dev, mlp_in, raw, enc_in);
-            return check_launch("sample_features");
-        }
         auto kern = generic ? (lds_tail ? sample_features8_kernel<true, true> : sample_features8_kernel<true, false>)
                             : (lds_tail ? sample_features8_kernel<false, true> : sample_features8_kernel<false, false>);
-        const unsigned cohab_lds = lds_tail ? 0u : (unsigned)knob(kKnobCohabLds);       // experiment, see msknn_clustered
-        if (cohab_lds) {
-            if (blocks8 > (int64_t)kNumCU) blocks8 = kNumCU;
-            OCC_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)cohab_lds) == hipSuccess, "sample_features: hipFuncSetAttribute");
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks8), dim3(threads), cohab_lds, as_stream(stream), xyz,
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks8), dim3(threads), 0, as_stream(stream), xyz,
                            N, knn_idxs, reinterpret_cast<const float4 *>(point_geo),
                            reinterpret_cast<const float4 *>(point_tail),
                            reinterpret_cast<const float4 *>(table), reinterpret_cast<const float2 *>(embeddings),

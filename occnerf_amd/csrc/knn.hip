@@ -20,7 +20,9 @@
 // instructions each); support set 146 KB streamed through the scalar cache per wave.
 #include "common.h"
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include <cmath>
 #include <vector>
@@ -694,32 +696,39 @@ OCC_API int occnerf_msknn_clustered_centered(const float *xyz, const float *mask
     OCC_REQUIRE(tiles < (1ll << 31), "msknn_clustered: too many tiles for one launch");
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > (int64_t)kNumCU * 3) blocks = (int64_t)kNumCU * 3;      // 12 resident waves per CU at this register count
-    // experiment (OCCNERF_COHAB_LDS=<bytes>): one workgroup per CU, padded with unused LDS so that a CU holds at most one of
-    // them and exactly one canonical-MLP workgroup (78 112 B) beside it
-    const unsigned cohab_lds = (unsigned)knob(kKnobCohabLds);      // read once, clamped (common.hip)
-    if (cohab_lds) {
-        if (blocks > (int64_t)kNumCU) blocks = kNumCU;
-        OCC_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(msknn_clustered_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)cohab_lds) == hipSuccess,
-                    "msknn_clustered: hipFuncSetAttribute");
-    }
-    // ticket counter of this launch: a slot of a small per-device ring, zeroed on the launch stream
+    // Ticket counter of this launch: ONE 64-byte line per (device, stream), zeroed on the launch stream.  Launches on a stream
+    // are in order, so the memset of launch n + 1 cannot pass the kernel of launch n, and launches on different streams never
+    // share a line (round 5's 64-slot per-device ring could hand a line still in use on stream A to a launch on stream B, whose
+    // tickets the older kernel would then have drawn).  The lines come from one pool per device allocated at the first call
+    // (no allocation later, so a launch inside a stream capture is legal once any launch has happened outside one); a captured
+    // launch replays its own memset node and owns the capture stream's line.
+    constexpr int kTicketLines = 1024;
     static std::mutex mu;
-    static unsigned *ring[16] = {nullptr};
-    static unsigned next[16] = {0};
+    static std::map<int, unsigned *> pools;
+    static std::map<std::pair<int, void *>, unsigned *> lines;
     int dev = 0;
-    OCC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "msknn_clustered: device id");
+    OCC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0, "msknn_clustered: device id");
     unsigned *ticket;
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (!ring[dev]) OCC_REQUIRE(hipMalloc(&ring[dev], 64 * sizeof(unsigned)) == hipSuccess, "msknn_clustered: hipMalloc");
-        ticket = ring[dev] + (next[dev]++ & 63);
+        unsigned *&pool = pools[dev];
+        if (!pool)
+            OCC_REQUIRE(hipMalloc(&pool, kTicketLines * 64) == hipSuccess,
+                        "msknn_clustered: hipMalloc of the ticket lines (the first call must not be inside a stream capture)");
+        auto it = lines.find(std::make_pair(dev, stream));
+        if (it == lines.end()) {
+            int used = 0;
+            for (auto &kv : lines) used += kv.first.first == dev;
+            OCC_REQUIRE(used < kTicketLines, "msknn_clustered: more than %d streams on device %d", kTicketLines, dev);
+            it = lines.emplace(std::make_pair(dev, stream), pool + 16 * used).first;
+        }
+        ticket = it->second;
     }
     OCC_REQUIRE(hipMemsetAsync(ticket, 0, sizeof(unsigned), as_stream(stream)) == hipSuccess, "msknn_clustered: memset");
     if (query_rows)
         hipLaunchKernelGGL(ray_list_ranges_kernel, dim3((unsigned)((n_rays + 256) / 256)), dim3(256), 0, as_stream(stream),
                            query_rows, n_query_dev, n_rays, samples_per_ray, ray_start);
-    hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), cohab_lds, as_stream(stream), xyz, mask,
+    hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, mask,
                        n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points),
                        reinterpret_cast<const float4 *>(centers), reinterpret_cast<const int2 *>(cluster_ranges),
                        cluster_radius, reinterpret_cast<const float4 *>(group_centers),

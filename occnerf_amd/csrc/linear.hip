@@ -326,202 +326,6 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinearArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// linear_resident_kernel (round 5, bf16 only): the SAME product with the layer's whole weight matrix resident in LDS.
-// linear_kernel re-fetches the 64 KiB weight chunks for every 128 rows (as much L2 -> LDS traffic as the layer moves through
-// HBM) and serialises, per chunk, "DMA + x loads -> wait -> barrier -> 64 MFMAs": measured 210 us for a 786 432 x 256 x 256
-// layer whose HBM time is 128 us.  A bf16 layer of this network is at most 256 x 256 x 2 B = 128 KiB, which fits the CU's
-// 160 KiB: one persistent workgroup per CU loads it ONCE (same LDS-DMA, same XOR swizzle, K cut into two 256-byte chunks)
-// and then walks its row tiles with no barrier at all -- a wave's 32 rows are its own: the next tile's x fragments (and this
-// tile's ReLU-mask rows) are requested before the current tile's MFMAs, the result goes out through the wave's private LDS
-// tile in whole 128-byte lines.  One wave per SIMD (acc 128 + x 64 + mask 64 registers); the memory system is kept busy by
-// the prefetch distance, not by occupancy.
-// MEASURED (round 5, MI355X, the whole bf16 training step with 12 of its 20 layer launches on this kernel): 22.5 ms against
-// 19.6 ms with linear_kernel -- SLOWER by 2.9 ms, i.e. ~450 us per layer instead of 210.  At 512 registers hipcc still spills
-// (88 bytes of scratch in the 256-wide instantiation), and with a single wave per SIMD nothing covers the LDS operand reads
-// between dependent MFMAs (linear_kernel's two workgroups per CU do exactly that for each other).  A second form with EIGHT
-// waves per workgroup (two per SIMD, 256-row tiles, no mask prefetch, epilogue in half tiles to fit the LDS; knob = 2) is
-// slower still: 27.9 ms -- at 256 registers per wave hipcc spills 590 bytes of the 256-wide instantiation into scratch.
-// Not shipped: opt-in with the experiment knob linear_resident = 1 / 2 (OCCNERF_LINEAR_RESIDENT), bit-identical outputs
-// (same products, same order: tests/test_train_hip.py::test_linear_resident_experiment_matches_shipped_kernel).
-// WAVES = 4: one wave per SIMD, the next tile's x requested in place (the first form, measured slower than linear_kernel);
-// WAVES = 8 (knob linear_resident = 2): two waves per SIMD cover each other's LDS operand reads, 256-row tiles.
-template <int NB, int WAVES>
-constexpr int resident_lds_bytes() {
-    return 2 * NB * 32 * kChunkBytes + WAVES * 32 * (128 + 16) / (WAVES / 4) + NB * 32 * 4;
-}
-
-template <int NB, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 1) void linear_resident_kernel(const LinearArgs a) {
-    constexpr int N = NB * 32;
-    constexpr int kWBytes = 2 * N * kChunkBytes;
-    constexpr int kRows = WAVES * 32;                              // rows of a workgroup tile
-    constexpr int kHalf = WAVES / 4;                               // epilogue row groups per wave tile (8 waves: 2 x 16 rows, to fit LDS)
-    constexpr int kTileRows = 32 / kHalf;
-    constexpr int kTileBytes = kTileRows * (128 + 16);
-    __shared__ __attribute__((aligned(16))) char wl[resident_lds_bytes<NB, WAVES>()];
-    char *tiles = wl + kWBytes;
-    float *bias_lds = reinterpret_cast<float *>(tiles + WAVES * kTileBytes);
-    if (threadIdx.x < N) bias_lds[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.0f;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i = lane & 31, h = lane >> 5;
-    const int kb = a.k0 + a.k1;                                   // bytes of K, <= 512
-    const int64_t ldw = kb;
-    const unsigned wl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)wl;
-    // ---- the weight matrix -> LDS, once (chunk c = bytes [256 c, 256 c + 256) of every row) ----
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int cb = kb - c * kChunkBytes < kChunkBytes ? kb - c * kChunkBytes : kChunkBytes;
-        const int ppr = cb > 0 ? cb >> 4 : 0;
-#pragma unroll
-        for (int it = 0; it < NB * 8 / WAVES; it++) {
-            const int rb = wave * (NB * 32 / WAVES) + it * 4;
-            const int g = (lane & 15) ^ ((rb + (lane >> 4)) & 15);
-            if (g < ppr) {
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                             "s_mov_b32 m0, %0"
-                             : "=&s"(keep)
-                             : "v"((unsigned)((lane >> 4) * (int)ldw + g * 16)), "s"(a.W + rb * ldw + c * kChunkBytes),
-                               "s"(wl_lds + (unsigned)(c * N * kChunkBytes + rb * kChunkBytes))
-                             : "memory");
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int64_t ntiles = (a.M + kRows - 1) / kRows;
-    const int ngroups = kb >> 5;                                  // 32-byte K groups (16 elements), <= 16
-    // row pointers of a tile's x fragments (segment 0 / segment 1, the latter pre-shifted by k0)
-    auto row_ptrs = [&](int64_t tile, const char *&r0, const char *&r1) {
-        const int64_t m = tile * kRows + wave * 32 + i;
-        const int64_t ms = m < a.M ? m : a.M - 1;
-        r0 = a.x0 + ms * a.ld0 + h * 16;
-        r1 = a.k1 ? a.x1 + ms * a.ld1 + h * 16 - a.k0 : r0;
-    };
-    const bool out4 = a.out_f32 != 0;
-    char *ot = tiles + wave * kTileBytes;
-    u32x4 xc[16];
-    int64_t tile = blockIdx.x;
-    if (tile < ntiles) {
-        const char *r0, *r1;
-        row_ptrs(tile, r0, r1);
-#pragma unroll
-        for (int kg = 0; kg < 16; kg++)
-            if (kg < ngroups) xc[kg] = *reinterpret_cast<const u32x4 *>((kg * 32 < a.k0 ? r0 : r1) + kg * 32);
-    }
-#pragma unroll 1
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int64_t m0 = tile * kRows + wave * 32;
-        // this tile's ReLU-mask rows (input-gradient form): the first half of the passes requested before everything else
-        // (the epilogue then waits for them alone), the second half behind the MFMAs (they land under the first passes)
-        u32x4 mk[NB / 2][4];
-        auto load_mask = [&](int p) {
-#pragma unroll
-            for (int it = 0; it < 4; it++) {
-                const int pc = it * 64 + lane, r = pc >> 3, c = pc & 7;
-                mk[p][it] = u32x4{0u, 0u, 0u, 0u};
-                if (m0 + r < a.M) mk[p][it] = *reinterpret_cast<const u32x4 *>(a.mask + (m0 + r) * a.ldm + p * 128 + c * 16);
-            }
-        };
-        constexpr int kEarly = WAVES == 8 ? 0 : (NB / 2 > 2 ? 2 : NB / 2);      // (two waves per SIMD: no room to hold masks early)
-        if (a.mask && !out4) {
-#pragma unroll
-            for (int p = 0; p < kEarly; p++) load_mask(p);
-        }
-        // the NEXT tile's x fragments are requested IN PLACE: group kg's registers are dead once its MFMAs have issued, and
-        // the next tile reads them a whole tile later (>= 2 us: the prefetch distance), so no second buffer is held
-        const int64_t next = tile + gridDim.x;
-        const char *n0 = nullptr, *n1 = nullptr;
-        if (next < ntiles) row_ptrs(next, n0, n1);
-        f32x16 acc[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[nb][r] = 0.0f;
-#pragma unroll
-        for (int kg = 0; kg < 16; kg++) {
-            if (kg < ngroups) {
-                const char *wc = wl + (kg >> 3) * N * kChunkBytes + ((((2 * (kg & 7) + h) ^ (i & 15))) << 4);
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) {
-                    const u32x4 w = *reinterpret_cast<const u32x4 *>(wc + (nb * 32 + i) * kChunkBytes);
-                    acc[nb] = mma16<true>(w, xc[kg], acc[nb]);
-                }
-                if (n0) xc[kg] = *reinterpret_cast<const u32x4 *>((kg * 32 < a.k0 ? n0 : n1) + kg * 32);
-            }
-        }
-        if (WAVES == 4 && a.mask && !out4) {
-#pragma unroll
-            for (int p = kEarly; p < NB / 2; p++) load_mask(p);
-        }
-        // ---- epilogue: 128 bytes of every row per pass through the wave's private LDS tile (kHalf row groups of kTileRows) ----
-        constexpr int kIt = 4 / kHalf;                            // 16-byte pieces per lane per row group
-        const int il = i - (i / kTileRows) * kTileRows;           // row inside its group
-        if (out4) {
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) {
-#pragma unroll
-                for (int hh = 0; hh < kHalf; hh++) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int n = nb * 32 + 8 * q + 4 * h;
-                        const f32x4 v = out_quad<NB>(acc, nb, q, n, a, m0 + i, bias_lds);
-                        if (i / kTileRows == hh) *reinterpret_cast<f32x4 *>(ot + il * (128 + 16) + (n - nb * 32) * 4) = v;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int it2 = 0; it2 < kIt; it2++) {
-                        const int pc = (hh * kIt + it2) * 64 + lane, r = pc >> 3, c = pc & 7;
-                        if (m0 + r < a.M)
-                            *reinterpret_cast<u32x4 *>(a.y + (m0 + r) * a.ldy + nb * 128 + c * 16) =
-                                *reinterpret_cast<const u32x4 *>(ot + (r - hh * kTileRows) * (128 + 16) + c * 16);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            }
-        } else {
-#pragma unroll
-            for (int p = 0; p < NB / 2; p++) {
-                if (WAVES == 8 && a.mask) load_mask(p);          // this pass's mask rows, in flight under the LDS transposition
-#pragma unroll
-                for (int hh = 0; hh < kHalf; hh++) {
-#pragma unroll
-                    for (int nb = 2 * p; nb < 2 * p + 2; nb++) {
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int n = nb * 32 + 8 * q + 4 * h;
-                            const f32x4 v = out_quad<NB>(acc, nb, q, n, a, m0 + i, bias_lds);
-                            u32x2 o;
-                            o[0] = pack_bf16(v[0], v[1]);
-                            o[1] = pack_bf16(v[2], v[3]);
-                            if (i / kTileRows == hh) *reinterpret_cast<u32x2 *>(ot + il * (128 + 16) + (n - p * 64) * 2) = o;
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int it2 = 0; it2 < kIt; it2++) {
-                        const int it = hh * kIt + it2;
-                        const int pc = it * 64 + lane, r = pc >> 3, c = pc & 7;
-                        if (m0 + r >= a.M) continue;
-                        u32x4 v = *reinterpret_cast<const u32x4 *>(ot + (r - hh * kTileRows) * (128 + 16) + c * 16);
-                        if (a.mask) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                if (!((int32_t)(mk[p][it][e] << 16) > 0)) v[e] &= 0xffff0000u;
-                                if (!((int32_t)(mk[p][it][e] & 0xffff0000u) > 0)) v[e] &= 0x0000ffffu;
-                            }
-                        }
-                        *reinterpret_cast<u32x4 *>(a.y + (m0 + r) * a.ldy + p * 128 + c * 16) = v;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 struct WgradArgs {
     const char *dz;       // [M][n_pad] element type
     int64_t lddz;         // bytes
@@ -776,27 +580,6 @@ __global__ void pack_kernel(const float *__restrict__ W, const float *__restrict
 template <bool BF16>
 static int launch_linear(const LinearArgs &a, int n_pad, hipStream_t st) {
     const unsigned blocks = (unsigned)((a.M + kRowsPerWG - 1) / kRowsPerWG);
-    if constexpr (BF16) {
-        // EXPERIMENT (knob linear_resident = 1; measured slower, see the kernel): the weight-resident persistent kernel
-        const bool full = a.n_store == n_pad && !(a.mask && a.out_f32) && (n_pad % 64 == 0 || a.out_f32);
-        const int rk = knob(kKnobLinearResident);
-        if (full && a.k0 + a.k1 <= 2 * kChunkBytes && a.M >= 16384 && rk >= 1) {
-            const unsigned pb = blocks < (unsigned)kNumCU ? blocks : (unsigned)kNumCU;
-            switch (n_pad / 32) {
-#define OCC_RES_CASE(NB)                                                                            \
-    case NB:                                                                                        \
-        if (rk == 2) hipLaunchKernelGGL((linear_resident_kernel<NB, 8>), dim3(pb), dim3(512), 0, st, a);  \
-        else hipLaunchKernelGGL((linear_resident_kernel<NB, 4>), dim3(pb), dim3(256), 0, st, a);          \
-        return check_launch("linear_forward");
-                OCC_RES_CASE(2)
-                OCC_RES_CASE(4)
-                OCC_RES_CASE(6)
-                OCC_RES_CASE(8)
-#undef OCC_RES_CASE
-                default: break;
-            }
-        }
-    }
     switch (n_pad / 32) {
 #define OCC_LIN_CASE(NB)                                                                                 \
     case NB:                                                                                             \

@@ -538,7 +538,7 @@ __device__ __forceinline__ void lds_bias(f32x16 (&acc)[OB], const float *aux, in
     }
 }
 
-template <typename P, bool STAMP = false, bool SPREAD = true>
+template <typename P>
 __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     const float *__restrict__ mlp_in, const int32_t *__restrict__ in_rows /*nullable: input row of entry n*/, int64_t N_max,
     const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/, const float *__restrict__ pk,
@@ -548,13 +548,6 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     constexpr float kSx = P::kSx, kInvSx = 1.0f / P::kSx;
     const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
     if ((int64_t)blockIdx.x * 128 >= N) return;      // launches are sized for the worst case; uniform per workgroup
-    // STAMP (experiment knob split_refill = 2 / 3, tools/split_kernel_phases.py): s_memtime at the phase boundaries; workgroup 1000's
-    // wave 0 writes the differences over its own output rows (that tile's results are lost: a diagnostic launch)
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, tsplit = 0, tmark = 0;
-#define OCC_STAMP(V) if constexpr (STAMP) V = __builtin_amdgcn_s_memtime();
-#define OCC_SPLIT_BEGIN() if constexpr (STAMP) tmark = __builtin_amdgcn_s_memtime();
-#define OCC_SPLIT_END() if constexpr (STAMP) tsplit += __builtin_amdgcn_s_memtime() - tmark;
-    OCC_STAMP(st0)
     // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read)
     __shared__ __attribute__((aligned(16))) V8 smem[kRingSlots * kChunkUnits + Aux::kTotal / 4];
     V8 *ring = smem;
@@ -592,7 +585,6 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
             bx[s] = split8t<P>(v);
         }
     }
-    OCC_STAMP(st1)
     __syncthreads();
 
     // ---- weight stream: chunk g lives in ring slot g & 3 ----
@@ -618,9 +610,9 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     const V8 *slot_ = ring + (g & (kRingSlots - 1)) * kChunkUnits; \
     g++;
 
-    // SPREAD (the default; experiment knob split_refill = 1 turns it off): the four LDS-DMA pieces of the refill are not issued
+    // The four LDS-DMA pieces of the refill are not issued
     // right behind the barrier, amid the 16 ds_read_b128 of the k-step (where one piece costs the issuing wave 100-185 cycles:
-    // MI355X_MICROARCH.md), but one by one in the second half of the k-step's MFMAs.  Measured with the STAMP form
+    // MI355X_MICROARCH.md), but one by one in the second half of the k-step's MFMAs.  Measured with s_memtime stamps
     // (profiles/r05_split_kernel_phases.md): a hidden layer 17.5 K instead of 19.0 K cycles, a tile 147.7 K instead of 153.5 K,
     // the launch 39.8 instead of 40.3 ms -- two thirds of the cycles saved come back as a lower clock
     auto issue_piece = [&](int g, int f) {
@@ -636,17 +628,6 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     // one 16-wide k-step per chunk, 8 output blocks
 #define OCC_LAYER_LDS8(STEPS, ACC, BOPS)                                                   \
     _Pragma("unroll") for (int s_ = 0; s_ < (STEPS); s_++) {                               \
-        if constexpr (!SPREAD) {                                                           \
-            OCC_CHUNK_ENTER()                                                              \
-            V8 ah_[kOB], al_[kOB];                                                         \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ah_[ob_] = slot_[ob_ * 64 + lane];         \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) al_[ob_] = slot_[(kOB + ob_) * 64 + lane]; \
-            const Split &b_ = BOPS(s_);                                                    \
-            const V8 b3_ = P::third(b_.hi);                                                \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.hi, ACC[ob_]); \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(ah_[ob_], b_.lo, ACC[ob_]); \
-            _Pragma("unroll") for (int ob_ = 0; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(al_[ob_], b3_, ACC[ob_]);   \
-        } else {                                                                           \
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                               \
             __builtin_amdgcn_s_barrier();                                                  \
             const V8 *slot_ = ring + (g & (kRingSlots - 1)) * kChunkUnits;                 \
@@ -665,7 +646,6 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
             OCC_PIECE(2)                                                                   \
             _Pragma("unroll") for (int ob_ = 4; ob_ < kOB; ob_++) ACC[ob_] = P::mfma(al_[ob_], b3_, ACC[ob_]); \
             OCC_PIECE(3)                                                                   \
-        }                                                                                  \
     }
 
     f32x16 acc[kOB];
@@ -675,20 +655,14 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     lds_bias<kOB>(acc, aux + Aux::kGeoL0B, h);
 #define BOPS_X(s) bx[s]
     OCC_LAYER_LDS8(kS_L0Geo, acc, BOPS_X)
-    OCC_SPLIT_BEGIN()
     relu_split(bact, acc);
-    OCC_SPLIT_END()
-    OCC_STAMP(st2)
 #define BOPS_ACT(s) bact[s]
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
         lds_bias<kOB>(acc, aux + Aux::kGeoHB + l * 256, h);
         OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
-        OCC_SPLIT_BEGIN()
         if (l < 2) relu_split(bact, acc);
-        OCC_SPLIT_END()
     }
-    OCC_STAMP(st3)
     float sigma;
     {
         const f32x4 *W4 = reinterpret_cast<const f32x4 *>(aux + Aux::kSigma);
@@ -704,10 +678,7 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         }
         sigma = (sacc + __shfl_xor(sacc, 32)) * kInvSx + aux[Aux::kSigma + 256];
     }
-    OCC_SPLIT_BEGIN()
     relu_split(bact, acc);
-    OCC_SPLIT_END()
-    OCC_STAMP(st4)
     // geometry head: 2 output blocks; a chunk carries 4 k-steps [step][hi|lo][ob][lane]
     f32x16 geo[2];
     lds_bias<2>(geo, aux + Aux::kGeoHeadB, h);
@@ -744,24 +715,17 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         }
     }
 
-    OCC_STAMP(st5)
     // ---------------- colour trunk ----------------
     lds_bias<kOB>(acc, aux + Aux::kRgbL0B, h);
 #define BOPS_RGB0(s) ((s) < 4 ? bgeo[(s) & 3] : bx[((s) - 4) < 0 ? 0 : ((s) - 4)])
     OCC_LAYER_LDS8(kS_L0Rgb, acc, BOPS_RGB0)
-    OCC_SPLIT_BEGIN()
     relu_split(bact, acc);
-    OCC_SPLIT_END()
-    OCC_STAMP(st6)
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
         lds_bias<kOB>(acc, aux + Aux::kRgbHB + l * 256, h);
         OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
-        OCC_SPLIT_BEGIN()
         if (l < 2) relu_split(bact, acc);
-        OCC_SPLIT_END()
     }
-    OCC_STAMP(st7)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the 3 tail chunks: nobody reads them
     float rgb[3];
 #pragma unroll
@@ -786,21 +750,6 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         o[2] = rgb[2];
         o[3] = sigma;
     }
-    if constexpr (STAMP) {
-        st8 = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 1000 && wave == 0 && lane < 10) {
-            const unsigned long long d[10] = {st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4, st6 - st5, st7 - st6,
-                                              st8 - st7, st8 - st0, tsplit};
-            float dv = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 10; i++)
-                if (lane == i) dv = (float)d[i];
-            raw[n * 5] = dv;
-        }
-    }
-#undef OCC_STAMP
-#undef OCC_SPLIT_BEGIN
-#undef OCC_SPLIT_END
 #undef BOPS_X
 #undef BOPS_ACT
 #undef BOPS_RGB0
@@ -880,10 +829,7 @@ static int mlp_bf16x3_launch(const float *mlp_in, const int32_t *in_rows, int64_
     const int64_t blocks = (N_max + 127) / 128;
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_bf16x3: N too large");
     const bf16x8 *pkh = reinterpret_cast<const bf16x8 *>(packed_bf16);
-    if (variant == 0 && knob(kKnobSplitRefill) == 1)
-        hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<Bf16x3, false, false>), dim3((unsigned)blocks), dim3(256), 0,
-                           as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
-    else if (variant == 0)
+    if (variant == 0)
         hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<Bf16x3>), dim3((unsigned)blocks), dim3(256), 0,
                            as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
     else
@@ -912,12 +858,7 @@ OCC_API int occnerf_canonical_mlp_f16x3(const float *mlp_in, const int32_t *in_r
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_f16x3: N too large");
     const f16x8 *pkh = reinterpret_cast<const f16x8 *>(packed_f16);
     const dim3 grid((unsigned)blocks), wg(256);
-    switch (knob(kKnobSplitRefill)) {      // 0: the shipped form; 1: refill pieces at the barrier; 2 / 3: the two with phase stamps
-        case 1: hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3, false, false>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw); break;
-        case 2: hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3, true, true>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw); break;
-        case 3: hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3, true, false>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw); break;
-        default: hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
-    }
+    hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
     return check_launch("canonical_mlp_f16x3");
 }
 

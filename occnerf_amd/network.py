@@ -123,6 +123,8 @@ class Network(nn.Module):
         are noticed by themselves through the parameters' version counters)."""
         self._ctx = self._packed = self._wconst = None
         self._ray_orders = {}
+        # the captured per-step graphs read the dropped constants at baked-in addresses (train_graph.py): drop them too
+        self.__dict__.pop('_per_step_graph', None)
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
@@ -270,7 +272,6 @@ class Network(nn.Module):
             if cfg.get('dedup_global_positions', False):
                 frows, fcount = ops.unique_heads(xyz, 3, frows, fcount, scan=scan_a, scan_count=count)
         self.last_head_counts = (fcount, None)
-        self._await_center(center)
         if cfg.get('knn_query_list', True):    # tiles formed over the listed samples only (same indices, tested)
             knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], rows=frows, count=fcount, center=center)
         else:
@@ -357,49 +358,8 @@ class Network(nn.Module):
         # (the 4th entry pins what the cached row was computed from: ops.sample_features' freshness contract)
         return center, idx, ops.center_row(row[0], enc_in[0]), self._center_stamp(table)
 
-    @staticmethod
-    def _await_center(center):
-        """The centre tuple may have been produced on the side stream: its last entry is then the event to wait for."""
-        if center is not None and len(center) > 4 and center[4] is not None:
-            torch.cuda.current_stream(center[0].device).wait_event(center[4])
-
     def _center_stamp(self, table):
         return (table.data_ptr(), table._version, self.point_counter._version, self.cnl_mlp.module.encoder.embeddings._version)
-
-    def _side_stream(self, dev):
-        """The producer stream of the overlapped render (high priority: its small VALU / texture-path workgroups take the
-        slots the matrix-pipe kernel's retiring workgroups free)."""
-        s = getattr(self, '_producer', None)
-        if s is None or s.device != dev:
-            s = self._producer = torch.cuda.Stream(device=dev, priority=int(os.environ.get('OCC_PRODUCER_PRIORITY', '-1')))
-        return s
-
-    def _render_overlapped(self, chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann, table, pack, boxes=None, center=None):
-        """The frame's rays in `chunks` = [(rays8 slice, out_rows slice or None, out tensors)], software-pipelined over two streams: chunk k + 1's
-        sampler / warp / non-rigid MLP / kNN / feature kernels (producer stream) run while chunk k's canonical MLP and
-        compositing do (the caller's stream).  The kNN kernel is VALU-bound and the feature kernel texture-path-bound; the
-        canonical MLP leaves both almost idle (and they leave the matrix pipe idle), so the two halves fill different units
-        of the same CUs.  Same kernels on the same inputs as the serial order: bit-identical pixels (tested)."""
-        cfg = self.cfg
-        S = int(cfg.N_samples)
-        dev = chunks[0][0].device
-        main, prod = torch.cuda.current_stream(dev), self._side_stream(dev)
-        pk = self._packed_weights()
-        t_vals = torch.linspace(0., 1., steps=S, device=dev)
-        prod.wait_stream(main)
-        for rays8, out_rows, out in chunks:
-            with torch.cuda.stream(prod):
-                z, xyz, mask, _ = ops.sample_warp(rays8, S, t_vals, Rs, Ts, vol, bbox_min, bbox_scale, boxes=boxes)
-                st = self._stage_features(rays8, z, xyz, mask, pk, cond, hann, table, pack, center)
-                del xyz
-                ready = prod.record_event()
-            main.wait_event(ready)
-            for v in st.values():                    # produced on `prod`, consumed (and released) on `main`
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(main)
-            self._stage_mlp_composite(st, bgcolor, out, out_rows)
-            del st
-        # (nothing to join: the consumer stream is the caller's, and every producer kernel precedes a consumer wait)
 
     def _render_rays(self, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann,
                      table, t_rand=None, out=None, out_rows=None, pack=None, boxes=None, center=None):
@@ -428,7 +388,6 @@ class Network(nn.Module):
                 ops.nonrigid_bf16x3(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'], out=xyz)
             else:
                 ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
-        self._await_center(center)
         if cfg.get('knn_culling', True):     # same results, ~5x fewer distance evaluations
             knn = ops.msknn_clustered(xyz, rays8.shape[0], S, ctx['clusters'], ctx['seed'], center=center)
         else:
@@ -547,28 +506,12 @@ class Network(nn.Module):
                 cond = f32(dst_posevec).reshape(-1) if iter_val >= nr.kick_in_iter else \
                     torch.zeros(dst_posevec.numel(), device=dev)
                 # The collapse point's chain (its non-rigid offset, its neighbour lists and radius, its feature row: three
-                # single-workgroup kernels, ~0.2 ms of pure latency) is first needed by the kNN stage, milliseconds from now.
-                # cfg.center_side_stream (OFF by default) runs it on a side stream beside the pose chain, the volume softmax,
-                # the bone boxes, the warp and the non-rigid MLP, the kNN launch waiting for its event.  Measured (round 5,
-                # tools/center_stream_ab.py and bench.py under OCC_BENCH_CFG): a 22 784-ray share takes 20.13 instead of
-                # 20.29 ms in a steady loop, but through bench.py's emulated-rank leg -- a new shard size every few frames --
-                # the slowest of 8 ranks takes 21.4 instead of 20.7 ms (tensors born on the side stream live in that stream's
-                # allocator pool and are released through record_stream: every new size costs fresh device allocations).
+                # single-workgroup kernels) runs on the caller's stream like everything else.  (Round 5 carried an opt-in
+                # side-stream placement and a two-stream chunk pipeline; both measured neutral to negative and were removed in
+                # round 6 -- the renderer uses ONE stream, HISTORY.md 3.7.)
                 center = None
                 if cfg.get('knn_center_cache', True) and cfg.get('knn_culling', True):
-                    main = torch.cuda.current_stream(dev)
-                    if cfg.get('center_side_stream', False):
-                        side = self._side_stream(dev)
-                        side.wait_stream(main)
-                        with torch.cuda.stream(side):
-                            center = self._knn_center(cond, hann.tolist(), wc['table'], pack)
-                            ready = torch.cuda.Event()
-                            ready.record(side)
-                        for t in center[:3]:
-                            t.record_stream(main)
-                        center = center + (ready,)
-                    else:
-                        center = self._knn_center(cond, hann.tolist(), wc['table'], pack)
+                    center = self._knn_center(cond, hann.tolist(), wc['table'], pack)
                 Rs, Ts = ops.pose_motion_bases(self.pose_decoder, f32(dst_posevec).reshape(-1), refine, f32(dst_Rs[0]),
                                                f32(dst_Ts[0]), f32(cnl_gtfms[0]))
                 vol = ops.prior_softmax(wc['dec'], f32(motion_weights_priors[0]))
@@ -589,16 +532,7 @@ class Network(nn.Module):
                             - torch.cuda.memory_allocated(dev))
                     cap = min(cap, max(1 << 22, int(free // 2 // 470)))
                 rays_per_pass = max(1, cap // S)
-                n_over = int(cfg.get('overlap_chunks', 0))
-                overlap = (n_over > 1 and R >= n_over * 1024 and cfg.get('skip_empty_samples', True) and
-                           cfg.get('knn_culling', True))
-                if overlap:      # chunks of whole 256-ray blocks (four kNN tiles), two streams (see _render_overlapped)
-                    per = min(rays_per_pass, -(-R // (n_over * 256)) * 256)
-                    chunks = [(rays8[i:i + per], None if order is None else order[i:i + per],
-                               out if order is not None else tuple(t[i:i + per] for t in out)) for i in range(0, R, per)]
-                    self._render_overlapped(chunks, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                            wc['table'], pack, boxes, center)
-                for i in range(0, 0 if overlap else R, rays_per_pass):
+                for i in range(0, R, rays_per_pass):
                     n = min(rays_per_pass, R - i)
                     if order is not None:
                         self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),

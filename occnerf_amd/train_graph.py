@@ -9,14 +9,21 @@ The reference has the same structure (trainer.py:239-249 over network.py:558-596
 Here the whole part is captured ONCE, forward and backward, with `torch.cuda.make_graphed_callables` (hipGraph on ROCm) and
 replayed every step: static input buffers, one graph launch forward, one backward, parameter gradients handed to autograd
 as usual.  The capture is keyed on the data pointers of the parameters it reads and on the input shapes: an optimiser that
-updates in place (occnerf_amd/optim.FusedAdam, torch.optim.*) never triggers a re-capture; `load_state_dict`, `.to()` or a
-new point cloud do, once.
+updates in place (occnerf_amd/optim.FusedAdam, torch.optim.*) never triggers a re-capture; `Network.invalidate_cache()` -- which
+`load_state_dict`, `.to()` / `_apply` and a new point cloud all run -- drops the captured graphs together with the device-side
+constants they baked addresses of (the normals of `Network._context()`), so the next step captures afresh; an entry also keeps
+references to those constants, so nothing a live graph reads can be freed under it.
+
+A captured callable owns ONE set of static outputs and saved activations.  A second grad-enabled forward before the first one's
+backward (gradient accumulation over frames, a loss over two frames) would overwrite them: such a call is detected (the previous
+outputs are still alive and no gradient has reached them) and served by the eager modules instead -- correct, slower.
 
 Nothing numerical changes: the graph holds the very kernels the eager modules launch (the only edit for capturability is
 `torch.linalg.inv_ex` in place of `torch.inverse`, whose error check reads `info` on the host -- same rocSOLVER kernels).
 `cfg.train_graph = False` or any failure to capture (reported once through `warnings`) falls back to the eager modules.
 """
 import warnings
+import weakref
 
 import torch
 import torch.nn as nn
@@ -34,6 +41,9 @@ class _StaticPart(nn.Module):
         self.mweight_vol_decoder = net.mweight_vol_decoder
         self.point_dist = net.point_dist
         self.__dict__['net'] = net
+        # the graph bakes in the addresses of these per-model constants (train_path.point_sdf_block reads them): keep them alive
+        ctx = net._context()
+        self.__dict__['held'] = tuple(ctx[k] for k in ('normals', 'unit') if k in ctx)
         self.refine = bool(refine)
         self.total_bones = int(net.cfg.total_bones)
 
@@ -53,7 +63,9 @@ class PerStepGraph:
         self.entries = {}            # (refine, shapes) -> (callable, parameter data pointers)
         self.captures = 0            # how many times a graph was captured (tests: stays 1 over many steps)
         self.replays = 0
+        self.eager_fallbacks = 0     # grad-enabled calls served by the eager modules because a replay was still outstanding
         self.failed = None
+        self._pending = None         # weakref to the last replay's first output while its backward has not run
 
     def _param_key(self, mod):
         return tuple(p.data_ptr() for p in mod.parameters()) + (self.net.point_base.data_ptr(),)
@@ -61,6 +73,9 @@ class PerStepGraph:
     def __call__(self, refine, posevec, dst_Rs, dst_Ts, cnl_gtfms, prior):
         """-> (Rs, Ts, vol, knn_base, sdf), differentiable w.r.t. the parameters; None when graphs are unavailable."""
         if self.failed is not None:
+            return None
+        if self._pending is not None and self._pending() is not None:
+            self.eager_fallbacks += 1                         # the last replay's outputs are alive and not yet backpropagated
             return None
         args = tuple(t.detach().float().contiguous() for t in (posevec, dst_Rs, dst_Ts, cnl_gtfms, prior))
         key = (bool(refine),) + tuple(tuple(a.shape) for a in args)
@@ -87,7 +102,18 @@ class PerStepGraph:
             self.captures += 1
             hit = self.entries[key] = (fn, self._param_key(mod), mod)
         self.replays += 1
-        return hit[0](*args)
+        outs = hit[0](*args)
+        if torch.is_grad_enabled():
+            live = [o for o in outs if torch.is_tensor(o) and o.requires_grad]
+            if live:
+                self._pending = weakref.ref(live[0])
+
+                def done(grad, owner=self):
+                    owner._pending = None
+                    return grad
+                for o in live:
+                    o.register_hook(done)
+        return outs
 
 
 def get(net):

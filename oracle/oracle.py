@@ -24,11 +24,45 @@ def build():
     subprocess.check_call(['make', '-s', '-C', _HERE])
 
 
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask, cut by the cgroup's CPU quota when there is one (libgomp and torch
+    size their pools from the mask alone; under a quota that is oversubscription with spinning barriers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def set_threads(n):
+    """Size the oracle's OpenMP team (libgomp is in the process once the oracle is loaded)."""
+    lib()
+    try:
+        C.CDLL('libgomp.so.1').omp_set_num_threads(int(n))
+    except OSError:
+        pass
+    return int(n)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
+        # (before libgomp initialises: idle team members sleep instead of spinning -- the tests alternate between OpenMP
+        # regions, torch's own pool and GPU waits, and a spinning team of every host core starves all three)
+        os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
+        os.environ.setdefault('OMP_NUM_THREADS', str(effective_cpus()))
         _lib = C.CDLL(_LIB_PATH)
         _lib.oc_version.restype = C.c_int
     return _lib

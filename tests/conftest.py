@@ -1,5 +1,9 @@
+import faulthandler
 import os
+import signal
 import sys
+import threading
+import time
 
 import pytest
 
@@ -8,8 +12,84 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _cap_host_threads():
+    """Before torch / numpy / libgomp start their pools: at most 32 threads each, never more than the CPUs this process may use
+    (affinity mask AND cgroup quota), idle OpenMP threads asleep.  The CPU work of this suite is small (the oracle at sizes
+    that take seconds); what it must never do is spin a team of every host core beside a GPU test on a box whose container
+    grants a fraction of them -- the one way a 4-minute suite becomes a 20-minute one without any test being wrong."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    n = str(max(1, min(n, 32)))
+    for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
+        os.environ.setdefault(k, n)
+    os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
+
+
+_cap_host_threads()
+
+# Per-test watchdog (round 6; GPUTEST_r05 was killed at the driver's limit without naming the test it was in):
+#   * at OCC_TEST_DUMP_S seconds faulthandler writes every thread's Python stack to stderr (the test goes on);
+#   * at OCC_TEST_LIMIT_S seconds SIGALRM raises in the main thread, so a test stuck in Python, in a subprocess wait or in an
+#     interruptible system call FAILS by name;
+#   * at OCC_TEST_LIMIT_S + 30 a daemon thread prints the test's name and ends the process with os._exit(3): a main thread
+#     blocked inside a native call that never returns (a GPU wait) cannot run a signal handler.  Nothing is restarted or
+#     re-executed -- the session ends, non-zero, with the culprit on the last line.
+DUMP_S = int(os.environ.get('OCC_TEST_DUMP_S', '90'))
+LIMIT_S = int(os.environ.get('OCC_TEST_LIMIT_S', '180'))
+
+
+class TestTimeout(Exception):
+    pass
+
+
+_watch = {'name': None, 'deadline': None}
+
+
+def _hard_stop():
+    while True:
+        time.sleep(1.0)
+        name, deadline = _watch['name'], _watch['deadline']
+        if name is not None and deadline is not None and time.monotonic() > deadline:
+            sys.stderr.write(f'\nWATCHDOG: {name} did not return within {LIMIT_S + 30} s (blocked in native code); '
+                             'ending the session\n')
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+            os._exit(3)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    faulthandler.enable(file=sys.stderr, all_threads=True)
+    threading.Thread(target=_hard_stop, name='occ-test-watchdog', daemon=True).start()
+
+
+def _on_alarm(signum, frame):
+    raise TestTimeout(f'{_watch["name"]} exceeded {LIMIT_S} s')
+
+
+@pytest.fixture(autouse=True)
+def _per_test_watchdog(request):
+    _watch['name'] = request.node.nodeid
+    _watch['deadline'] = time.monotonic() + LIMIT_S + 30
+    faulthandler.dump_traceback_later(DUMP_S, repeat=False, file=sys.stderr, exit=False)
+    main = threading.current_thread() is threading.main_thread()
+    if main:
+        old = signal.signal(signal.SIGALRM, _on_alarm)
+        signal.alarm(LIMIT_S)
+    try:
+        yield
+    finally:
+        if main:
+            signal.alarm(0)
+            signal.signal(signal.SIGALRM, old)
+        faulthandler.cancel_dump_traceback_later()
+        _watch['name'] = None
+        _watch['deadline'] = None
 
 
 @pytest.fixture(scope='session')
@@ -17,3 +97,30 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from occnerf_amd import ops as o
+    return o
+
+
+_case_memo = {}
+
+
+def _golden_cases():
+    from tests import util
+    return util.GOLDEN_CASES
+
+
+@pytest.fixture(scope='module', params=_golden_cases())
+def case(request, oracle):
+    """(golden fixture, oracle-side model context, the oracle's stage-by-stage render of it); computed once per session."""
+    from tests import util
+    from tests.gpu_util import stagewise_oracle_render
+    name = request.param
+    if name not in _case_memo:
+        g = util.load_golden(name)
+        ctx = util.model_context(int(g['meta.seed']), util.level(g))
+        _case_memo[name] = (g, ctx, stagewise_oracle_render(g, ctx))
+    return _case_memo[name]

@@ -27,7 +27,7 @@ def test_python_binding_covers_the_header():
     from occnerf_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.lib()
-    assert lib.occnerf_abi_version() == 4
+    assert lib.occnerf_abi_version() == 5
     assert lib.occnerf_canonical_mlp_packed_floats() == 479812 + 0 or lib.occnerf_canonical_mlp_packed_floats() > 461568
 
 
@@ -39,6 +39,28 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc != 0 and b'null' in lib.occnerf_last_error()
     rc = lib.occnerf_grad_total_variation(None, None, None, None, 0.0, 0, 0, 0, 0, 0.0, 0, 0, 0, None)
     assert rc != 0 and b'not implemented' in lib.occnerf_last_error()
+
+
+def test_reference_native_module_names_import():
+    """the reference binds its operators as `import _gridencoder` (gridencoder/grid.py:9) and `import _shencoder`
+    (shencoder/sphere_harmonics.py:9); both names resolve from the repo root, the first to the three pybind names of
+    src/bindings.cpp:5-9 bound to the HIP library, the second to two by-name refusals."""
+    import inspect
+    import _gridencoder
+    import _shencoder
+    from occnerf_amd import ops
+    assert _gridencoder.grid_encode_forward is ops.grid_encode_forward
+    assert _gridencoder.grid_encode_backward is ops.grid_encode_backward
+    assert _gridencoder.grad_total_variation is ops.grad_total_variation
+    # positional order of the reference's calls (grid.py:55,83; shencoder.h:9-10)
+    assert list(inspect.signature(_gridencoder.grid_encode_forward).parameters) == [
+        'inputs', 'embeddings', 'offsets', 'outputs', 'B', 'D', 'Cc', 'L', 'S', 'H', 'dy_dx', 'gridtype', 'align_corners', 'interp']
+    assert list(inspect.signature(_gridencoder.grid_encode_backward).parameters) == [
+        'grad', 'inputs', 'embeddings', 'offsets', 'grad_embeddings', 'B', 'D', 'Cc', 'L', 'S', 'H', 'dy_dx', 'grad_inputs',
+        'gridtype', 'align_corners', 'interp']
+    assert list(inspect.signature(_shencoder.sh_encode_forward).parameters) == ['inputs', 'outputs', 'B', 'D', 'C', 'dy_dx']
+    assert list(inspect.signature(_shencoder.sh_encode_backward).parameters) == ['grad', 'inputs', 'B', 'D', 'C', 'dy_dx',
+                                                                                 'grad_inputs']
 
 
 def test_product_never_imports_the_oracle():

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from tests import util
+from tests.gpu_util import DEV, T, same  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -162,3 +163,27 @@ def test_ray_order_kernel_walks_the_morton_curve():
         rays8[:, 3:6] = d
         assert torch.equal(ops.ray_order(rays8[:, 3:6]), o)
     assert ops.ray_order(d[:1]).tolist() == [0] and ops.ray_order(d[:0]).numel() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['t32', 'f32', 'c64'])
+def test_gen_rays(ops, tag):
+    """Device ray generation against what the reference's camera_util produced (rays_cameras.npz)."""
+    from occnerf_amd import rays as rays_mod
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'rays_cameras.npz'))
+    img = int(g[f'{tag}.img'])
+    K, E, lo, hi = g[f'{tag}.K'], g[f'{tag}.E'], g[f'{tag}.bbox_min'], g[f'{tag}.bbox_max']
+    rays8, mask = ops.gen_rays(K, E, img, img, lo, hi, DEV)
+    rays8, mask = rays8.cpu().numpy(), mask.cpu().numpy().astype(bool)
+    want_mask = g[f'{tag}.mask']
+    assert (mask != want_mask).sum() == 0
+    # float32 cameras: numpy's sgemm may round the two 3-term dot products differently (<= 1 ulp of O(1))
+    assert np.abs(rays8[:, 0:3] - g[f'{tag}.rays_o']).max() <= 1e-6
+    assert np.abs(rays8[:, 3:6] - g[f'{tag}.rays_d']).max() <= 1e-6
+    assert np.abs(rays8[want_mask, 6] - g[f'{tag}.near']).max() <= 2e-5
+    assert np.abs(rays8[want_mask, 7] - g[f'{tag}.far']).max() <= 2e-5
+    fr = rays_mod.frame_rays(K, E, img, img, lo, hi, DEV)
+    R = int(want_mask.sum())
+    assert fr['rays'].shape == (2, R, 3) and fr['near'].shape == (R, 1) and fr['far'].shape == (R, 1)
+    assert np.abs(fr['rays'][1].cpu().numpy() - g[f'{tag}.rays_d'][want_mask]).max() <= 1e-6
+    assert np.array_equal(fr['ray_mask'].cpu().numpy(), want_mask)

@@ -599,6 +599,62 @@ def test_per_step_hipgraph_matches_eager_and_is_captured_once():
 
 
 @pytest.mark.parametrize('amplify', [False, True])
+def test_per_step_hipgraph_survives_load_state_dict_and_two_forwards():
+    """ADVICE r05.  (a) `load_state_dict` copies in place (no parameter pointer moves) but `invalidate_cache()` drops the
+    device-side constants the captured graph baked the addresses of: the graphs are dropped with them, the next step captures
+    afresh and -- after the allocator has had every chance to reuse the freed blocks -- agrees with the eager path.
+    (b) two grad-enabled forwards before one backward (a loss over two frames): the second is served by the eager modules
+    instead of overwriting the first replay's static outputs; gradients equal the all-eager run's."""
+    from occnerf_amd import synth, train_graph
+    frames = [frame_to_device(synth.make_frame(img_size=32, pose72=synth.seeded_pose(s), orbit_frame=7 + s), DEV) for s in (2, 3)]
+
+    def loss_of(out):
+        return ((out['rgb'] - 0.5) ** 2).mean() + 0.5 * out['alpha'].mean() + 0.1 * out['comp_loss'].mean()
+
+    def grads(net):
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    def close(ga, gb):
+        assert sorted(ga) == sorted(gb)
+        for n in gb:
+            scale = float(gb[n].abs().max().clamp_min(1e-30))
+            assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * scale, n
+
+    nets = {}
+    for graph in (True, False):
+        net, _ = build_network(0, True, S=32, non_rigid=True)
+        net.cfg.perturb, net.cfg.train_graph = 0.0, graph
+        net.train()
+        nets[graph] = net
+    net_g, net_e = nets[True], nets[False]
+    loss_of(net_g(**frames[0], iter_val=1e7)).backward()
+    pg0 = train_graph.get(net_g)
+    assert pg0.captures == 1 and pg0.failed is None
+    # (a)
+    net_g.load_state_dict({k: v.clone() for k, v in net_g.state_dict().items()})
+    assert '_per_step_graph' not in net_g.__dict__
+    junk = [torch.full((n,), 3.0, device=DEV, dtype=torch.float64) for n in (6890 * 3, 6890 * 3, 6890, 13780 * 3, 1 << 20)]
+    for net in (net_g, net_e):
+        net.zero_grad(set_to_none=True)
+        loss_of(net(**frames[0], iter_val=1e7)).backward()
+    pg = train_graph.get(net_g)
+    assert pg is not pg0 and pg.captures == 1 and pg.replays == 1
+    close(grads(net_g), grads(net_e))
+    del junk
+    # (b)
+    for net in (net_g, net_e):
+        net.zero_grad(set_to_none=True)
+        o1 = net(**frames[0], iter_val=1e7)
+        o2 = net(**frames[1], iter_val=1e7)
+        (loss_of(o1) + loss_of(o2)).backward()
+    assert pg.eager_fallbacks == 1 and pg.replays == 2 and pg.captures == 1
+    close(grads(net_g), grads(net_e))
+    # ... and the graph is taken again once that backward has run
+    net_g.zero_grad(set_to_none=True)
+    loss_of(net_g(**frames[0], iter_val=1e7)).backward()
+    assert pg.replays == 3 and pg.eager_fallbacks == 1
+
+
 def test_fused_pose_chain_and_point_block_match_torch_autograd(amplify):
     """The two fused backward kernels of round 5 -- pose refiner -> Rodrigues -> forward kinematics -> inverse -> motion bases
     (csrc/preamble.hip pose_motion_bases_backward_kernel) and the per-point SDF block (csrc/features.hip
@@ -653,36 +709,43 @@ def test_fused_pose_chain_and_point_block_match_torch_autograd(amplify):
             assert v <= (2e-5 if mine else 1e-4), (n, v)
 
 
-def test_linear_resident_experiment_matches_shipped_kernel():
-    """The opt-in weight-resident persistent form of the linear kernel (experiment knob linear_resident = 1; measured SLOWER than
-    the shipped kernel, csrc/linear.hip) forms the same products in the same order: bit-identical outputs for the layer shapes
-    of the trunks -- 256 -> 256 with ReLU, the two-segment 96 + 96 -> 256 layer, the input-gradient form with its ReLU mask,
-    a fp32-output 256 -> 64 layer -- on a ragged 20 011-row batch."""
-    from occnerf_amd import _lib, train_ops as to
-    g = torch.Generator(device='cpu').manual_seed(3)
-    M = 20011
-    bf = torch.bfloat16
-
-    def rnd(*shape, scale=1.0):
-        return (torch.randn(*shape, generator=g) * scale).to(DEV)
-    x, x0, x1 = rnd(M, 256).to(bf), rnd(M, 96).to(bf), rnd(M, 96).to(bf)
-    W, W2, W3 = rnd(256, 256, scale=0.06).to(bf), rnd(256, 192, scale=0.08).to(bf), rnd(64, 256, scale=0.06).to(bf)
-    b = rnd(256)
-    mask = rnd(M, 256).to(bf)
-
-    def run_all():
-        return [to.linear_forward(x, 256, W, 256, True, bias=b, relu=True),
-                to.linear_forward(x0, 96, W2, 256, True, x1=x1, k1=96, bias=b, relu=True),
-                to.linear_forward(x, 256, W, 256, True, mask=mask),
-                to.linear_forward(x, 256, W3, 64, True, out_f32=True)]
-    outs = {}
-    for knob in (0, 1, 2):                                  # shipped kernel, 4-wave and 8-wave weight-resident forms
-        assert _lib.lib().occnerf_experiment_knob(b'linear_resident', knob) >= 0
-        try:
-            outs[knob] = run_all()
-            torch.cuda.synchronize()
-        finally:
-            _lib.lib().occnerf_experiment_knob(b'linear_resident', 0)
-    for k in (1, 2):
-        for a, c in zip(outs[0], outs[k]):
-            assert torch.equal(a, c), k
+def test_aggregate_autograd(ops):
+    """HIP neighbour aggregation (training path) against torch's gather + sum and its autograd."""
+    torch.manual_seed(0)
+    P, N, K, Fd = 6890, 3001, 40, 35
+    feats = torch.randn(P, Fd, device=DEV, requires_grad=True)
+    knn = torch.randint(0, P, (N, K), device=DEV, dtype=torch.int32)
+    knn[:, :5] = 7                                                  # heavy duplicates -> contended atomics
+    atts = torch.softmax(torch.randn(N, K, device=DEV), dim=1)
+    want = (atts[..., None] * feats[knn.long()]).sum(1)
+    got = ops.aggregate(feats, knn, atts)
+    assert (got - want).abs().max().item() <= 2e-6
+    gout = torch.randn(N, Fd, device=DEV)
+    gw, = torch.autograd.grad(want, feats, gout, retain_graph=True)
+    gg, = torch.autograd.grad(got, feats, gout)
+    assert (gg - gw).abs().max().item() <= 1e-4 * gw.abs().max().item()
+    # runs (round 5): consecutive samples with identical id lists -- hence identical weights, which are a function of the ids
+    # -- are summed in registers and scattered once; samples with an all-zero gradient row are skipped.  Runs of every length
+    # across chunk (64) and trip (8) boundaries, a zero row inside a run, zero rows at both ends, against float64 autograd.
+    N2 = 5000
+    ids = torch.randint(0, P, (N2, K), device=DEV, dtype=torch.int32)
+    w2 = torch.softmax(torch.randn(N2, K, device=DEV), dim=1)
+    lens = [1, 2, 7, 8, 9, 63, 64, 65, 130, 500, 3, 1, 1000]
+    pos = 11
+    for ln in lens:
+        ids[pos:pos + ln] = ids[pos]
+        w2[pos:pos + ln] = w2[pos]
+        pos += ln + 2
+    gout2 = torch.randn(N2, Fd, device=DEV)
+    gout2[:11] = 0
+    gout2[700:705] = 0
+    gout2[-50:] = 0
+    gout2[40] = 0
+    f64 = feats.detach().double().requires_grad_(True)
+    want2 = (w2.double()[..., None] * f64[ids.long()]).sum(1)
+    gw2, = torch.autograd.grad(want2, f64, gout2.double())
+    f32 = feats.detach().clone().requires_grad_(True)
+    got2 = ops.aggregate(f32, ids, w2)
+    assert (got2.double() - want2).abs().max().item() <= 2e-6          # (the forward copies a run's sum instead of gathering again)
+    gg2, = torch.autograd.grad(got2, f32, gout2)
+    assert (gg2.double() - gw2).abs().max().item() <= 2e-6 * gw2.abs().max().item()

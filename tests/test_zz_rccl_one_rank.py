@@ -6,7 +6,7 @@ import os
 import pytest
 import torch
 
-from tests.test_hip_parity import _torchrun
+from tests.gpu_util import _torchrun
 
 pytestmark = pytest.mark.gpu
 

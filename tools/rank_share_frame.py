@@ -17,12 +17,10 @@ ap.add_argument('--world', type=int, default=8)
 ap.add_argument('--rank', type=int, default=0)
 ap.add_argument('--frames', type=int, default=40)
 ap.add_argument('--dedup', action='store_true')
-ap.add_argument('--side-stream', action='store_true', help='collapse-point chain on a side stream (cfg.center_side_stream)')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 net = build_network(seed=0, amplify=False, S=128, non_rigid=True, device=dev)
 net.cfg.dedup_repeated_samples = args.dedup
-net.cfg.center_side_stream = args.side_stream
 data = frame_to_device(synth.make_frame(img_size=512, pose72=synth.seeded_pose(1), orbit_frame=28), dev)
 for k in ('cnl_bbox_min_xyz', 'cnl_bbox_scale_xyz', 'bgcolor'):
     data[k] = data[k].cpu()
