@@ -31,7 +31,8 @@ extern "C" {
 /* Bumped whenever an existing export's signature or a table layout changes (2: composite/msknn_clustered/
  * sample_features grew arguments in round 2, the Adam table row carries per-tensor bias corrections; 3: msknn_clustered
  * takes the cluster groups; 4: occnerf_agg_backward takes a scratch buffer; 5: round 6 -- the experiment knobs cohab_lds,
- * features_small, features_rowcache, linear_resident and split_refill and the kernels behind them left the library). */
+ * features_small, features_rowcache, linear_resident and split_refill and the kernels behind them left the library; the two
+ * f16x3 calls take a domain flag). */
 #define OCCNERF_ABI_VERSION 5
 
 int occnerf_abi_version(void);
@@ -116,6 +117,19 @@ int occnerf_grid_encode_forward_f16(const float *inputs, const void *embeddings,
 int occnerf_grid_encode_backward_f16(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets,
                                      void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                      uint32_t H, const void *dy_dx, void *grad_inputs, uint32_t gridtype, int align_corners,
+                                     uint32_t interp, void *stream);
+
+/* The double dispatch case (gridencoder.cu:467,500 with scalar_t = double): embeddings, outputs, dy_dx, grad, grad_embeddings,
+ * grad_inputs are float64; inputs stay float32 and so do the cell position, the corner weights and pos_deriv, exactly as the
+ * reference's templates leave them; products with the double tensors are formed in double and `r += a * b` is one fma
+ * (csrc/grid_encode_f64.hip).  The backward scatters with global_atomic_add_f64.  With the two calls above this completes
+ * AT_DISPATCH_FLOATING_TYPES_AND_HALF: no dtype the reference's `_gridencoder` accepts is refused. */
+int occnerf_grid_encode_forward_f64(const float *inputs, const double *embeddings, const int32_t *offsets, double *outputs,
+                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, double *dy_dx,
+                                    uint32_t gridtype, int align_corners, uint32_t interp, void *stream);
+int occnerf_grid_encode_backward_f64(const double *grad, const float *inputs, const double *embeddings, const int32_t *offsets,
+                                     double *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                     uint32_t H, const double *dy_dx, double *grad_inputs, uint32_t gridtype, int align_corners,
                                      uint32_t interp, void *stream);
 
 /* Total-variation gradient, gridencoder.cu:506-645.  Never called by the reference's
@@ -459,18 +473,21 @@ int occnerf_canonical_mlp_bf16x3_rows(const float *mlp_in, const int32_t *in_row
  * v_mfma_f32_32x32x16_f16 with every operand cut into two fp16 pieces kept in the normal range -- 22 significand bits per
  * operand (fp32: 24), three products, fp32 accumulation (csrc/split.h F16x3: activations travel scaled by 16, the weights'
  * low piece scaled by 2^11 against xh 2^-11; subnormal inputs are preserved by the instruction, measured with
- * tools/mfma_f16_probe.hip).  Domain: hidden activations below 65504 / 16 = 4 094 (larger ones saturate there).
+ * tools/mfma_f16_probe.hip).  Domain: hidden activations below 65504 / 16 = 4 094 (larger ones saturate there) -- and leaving
+ * it is REPORTED: domain_flag (nullable; a zero-initialised device word the caller owns) has bit 0 set by every wave in which a
+ * value reached the clamp, so the caller can re-evaluate with the fp32 kernels (Network.forward does).
  * packed_f16: the same byte count and layout as the bf16 stream (occnerf_canonical_mlp_packed_bf16_bytes /
  * occnerf_nonrigid_packed_bf16_bytes, zero-initialised), written by the _pack_f16 call; packed: the fp32 blob (biases, head
  * rows).  in_rows / rows and n_dev nullable (every row, N_max entries); with a list the count is read from device memory.
  * The non-rigid call may run in place (xyz_out == xyz_in); with rows the offsets go to the listed samples. */
 int occnerf_canonical_mlp_pack_f16(const float *const *h_W, void *packed_f16, void *stream);
 int occnerf_canonical_mlp_f16x3(const float *mlp_in, const int32_t *in_rows, int64_t N_max, const int32_t *n_dev,
-                                const float *packed, const void *packed_f16, float *raw, void *stream);
+                                const float *packed, const void *packed_f16, float *raw, uint32_t *domain_flag,
+                                void *stream);
 int occnerf_nonrigid_pack_f16(const float *const *h_W, void *packed_f16, void *stream);
 int occnerf_nonrigid_f16x3(const float *xyz_in, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
                            const float *cond, const float *h_hann, const float *W0, const float *b0, float *packed,
-                           const void *packed_f16, float *xyz_out, void *stream);
+                           const void *packed_f16, float *xyz_out, uint32_t *domain_flag, void *stream);
 
 /* Alpha compositing, network.py:320-348.  raw[n,S,5], mask[n*S], z_vals[n,S],
  * rays[n,8] (direction at floats 3..5), h_bgcolor[3] host, 0..255.

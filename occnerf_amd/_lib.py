@@ -32,6 +32,10 @@ SIGNATURES = {
                                                    _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grid_encode_backward_f16': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
                                                     _u32, _vp, _vp, _u32, C.c_int, _u32, _vp]),
+    'occnerf_grid_encode_forward_f64': (C.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32,
+                                                   _vp, _u32, C.c_int, _u32, _vp]),
+    'occnerf_grid_encode_backward_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
+                                                    _u32, _vp, _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grad_total_variation': (C.c_int, [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32,
                                                 _u32, _u32, C.c_int, _vp]),
     'occnerf_sample_warp': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
@@ -92,9 +96,9 @@ SIGNATURES = {
     'occnerf_canonical_mlp_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
     'occnerf_canonical_mlp_bf16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     'occnerf_canonical_mlp_pack_f16': (C.c_int, [_vp, _vp, _vp]),
-    'occnerf_canonical_mlp_f16x3': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_canonical_mlp_f16x3': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_nonrigid_pack_f16': (C.c_int, [_vp, _vp, _vp]),
-    'occnerf_nonrigid_f16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'occnerf_nonrigid_f16x3': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_canonical_mlp_bf16x3_rows': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
     'occnerf_composite': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_linear_pack': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -26,71 +26,10 @@
 // MFMA count per wave: 288 + 3*1024 + 256 + 544 + 3*1024 = 7232 (ideal 7212): 99.7 % of
 // the issued matrix work is algorithmic.  Roofline: fp32 MFMA, 157.3 TFLOP/s.
 #include "common.h"
+#include "mlp_layout.h"
 #include "split.h"
 
 namespace occ {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kWidth = 256;
-constexpr int kOB = kWidth / 32;     // 8 output blocks of 32 features
-constexpr int kInGeo = 68, kInRgb = 131;
-constexpr int kXRegs = 36;           // 34 input k-steps (68 features over two half-waves) + 2 pad
-constexpr int kG_L0Geo = kXRegs / 4;             // 9 groups of 4 k-steps
-constexpr int kG_Hidden = kWidth / 2 / 4;        // 32
-constexpr int kG_L0Rgb = (32 + kXRegs) / 4;      // 17
-
-// packed blob layout, in floats (every offset a multiple of 4 -> 16-byte aligned)
-constexpr int64_t wsz(int groups, int ob) { return (int64_t)groups * ob * 64 * 4; }
-struct Blob {
-    static constexpr int64_t kGeoL0W = 0;
-    static constexpr int64_t kGeoL0B = kGeoL0W + wsz(kG_L0Geo, kOB);
-    static constexpr int64_t kGeoHW = kGeoL0B + kWidth;                      // 3 x (W, B)
-    static constexpr int64_t kHiddenStride = wsz(kG_Hidden, kOB) + kWidth;
-    static constexpr int64_t kGeoHeadW = kGeoHW + 3 * kHiddenStride;
-    static constexpr int64_t kGeoHeadB = kGeoHeadW + wsz(kG_Hidden, 2);
-    static constexpr int64_t kSigmaW = kGeoHeadB + 64;
-    static constexpr int64_t kSigmaB = kSigmaW + kWidth;
-    static constexpr int64_t kRgbL0W = kSigmaB + 4;
-    static constexpr int64_t kRgbL0B = kRgbL0W + wsz(kG_L0Rgb, kOB);
-    static constexpr int64_t kRgbHW = kRgbL0B + kWidth;
-    static constexpr int64_t kOutW = kRgbHW + 3 * kHiddenStride;
-    static constexpr int64_t kOutB = kOutW + 3 * kWidth;
-    static constexpr int64_t kTotal = kOutB + 4;
-};
-
-// ---------------------------------------------------------------------------------------
-// weight packing
-// ---------------------------------------------------------------------------------------
-enum LayerKind { kL0Geo = 0, kHidden = 1, kGeoHead = 2, kL0Rgb = 3 };
-
-// feature of the layer's torch-layout input that k-step `t` carries in half-wave `h`
-// (-1: zero weight)
-__host__ __device__ inline int slot_feature(int kind, int t, int h) {
-    const int blk = t >> 4, r = t & 15;
-    const int cd = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // 32x32 C/D row of (reg, half)
-    switch (kind) {
-        case kL0Geo: return t < 34 ? h * 34 + t : -1;
-        case kHidden:
-        case kGeoHead: return cd;
-        case kL0Rgb: {
-            if (t < 32) return cd;                 // geometry features h[1:65] -> inputs 0..63
-            if (t >= 66) return -1;
-            const int m = h * 34 + (t - 32);       // position in [agg35, var, enc32]
-            if (m < 35) return 64 + m;             // aggregated point features
-            if (m == 35) return -1;                // var is not an input of the colour trunk
-            return 64 + 35 + (m - 36);             // hash encoding
-        }
-    }
-    return -1;
-}
-
-// torch-layout output row computed in packed row `row` (-1: padding row)
-__host__ __device__ inline int out_row(int kind, int row, int out_dim) {
-    if (kind == kGeoHead) return row < 64 ? row + 1 : -1;   // row 0 (sigma) handled by dot_rows
-    return row < out_dim ? row : -1;
-}
 
 __global__ void pack_layer_kernel(const float *__restrict__ W, const float *__restrict__ b,
                                   int kind, int in_dim, int out_dim, int groups, int ob_count,
@@ -283,10 +222,6 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_kernel(const float *__re
 // next layer's B operands after bias/ReLU and the hi/lo split (done in registers, 3 VALU per
 // value).  A k-step is now 16 wide: lane half h supplies 8 consecutive registers of a block.
 // =======================================================================================
-constexpr int kS_L0Geo = 5;                 // ceil(34 / 8) k-steps of 16 (8 per half-wave)
-constexpr int kS_Hidden = kWidth / 16;      // 16
-constexpr int kS_L0Rgb = 4 + 5;             // 64 geometry features + 34 x-slots
-
 // bf16 blob layout in units of bf16x8 (16 bytes): [step][hi|lo][ob][lane]
 constexpr int64_t bsz(int steps, int ob) { return (int64_t)steps * 2 * ob * 64; }
 struct BlobH {
@@ -367,7 +302,7 @@ __device__ __forceinline__ void load_step(bf16x8 (&ah)[OB], bf16x8 (&al)[OB], co
 
 // relu(acc) -> the 16 split B operands of the next layer (2 per 32-feature block)
 template <typename P>
-__device__ __forceinline__ void relu_split(SplitT<P> (&b)[2 * kOB], const f32x16 (&acc)[kOB]) {
+__device__ __forceinline__ void relu_split(SplitT<P> (&b)[2 * kOB], const f32x16 (&acc)[kOB], float &amax) {
 #pragma unroll
     for (int ob = 0; ob < kOB; ob++) {
 #pragma unroll
@@ -375,9 +310,16 @@ __device__ __forceinline__ void relu_split(SplitT<P> (&b)[2 * kOB], const f32x16
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = P::relu(acc[ob][sub * 8 + i]);
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) P::watch(amax, acc[ob][sub * 8 + i], acc[ob][sub * 8 + i + 1]);
             b[ob * 2 + sub] = split8t<P>(v);
         }
     }
+}
+template <typename P>
+__device__ __forceinline__ void relu_split(SplitT<P> (&b)[2 * kOB], const f32x16 (&acc)[kOB]) {
+    float unused = 0.0f;
+    relu_split<P>(b, acc, unused);
 }
 
 __device__ __forceinline__ float dot_row_relu(const f32x16 (&acc)[kOB], const float *__restrict__ Wrow, int h) {
@@ -512,18 +454,6 @@ struct Aux {
     static constexpr int kTotal = 3144;
 };
 
-// LDS-DMA of 64 x 16 B: wave-uniform source base (SGPR pair) + 32-bit lane offset ("saddr" form -- a
-// 64-bit VGPR address per lane costs the issuing SIMD ~40 cycles of matrix-pipe time per instruction on
-// gfx950), wave-uniform LDS destination in M0 (lane i lands at +16 i).
-__device__ __forceinline__ void glds16(const void *gbase, unsigned lane_off, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane_off), "s"(gbase), "s"(lds_dst)
-                 : "memory");
-}
-
 template <int OB>
 __device__ __forceinline__ void lds_bias(f32x16 (&acc)[OB], const float *aux, int h) {
     const f32x4 *B4 = reinterpret_cast<const f32x4 *>(aux);
@@ -542,9 +472,10 @@ template <typename P>
 __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     const float *__restrict__ mlp_in, const int32_t *__restrict__ in_rows /*nullable: input row of entry n*/, int64_t N_max,
     const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/, const float *__restrict__ pk,
-    const typename P::V8 *__restrict__ pkh, float *__restrict__ raw) {
+    const typename P::V8 *__restrict__ pkh, float *__restrict__ raw, uint32_t *__restrict__ domain_flag /*nullable*/) {
     typedef typename P::V8 V8;
     typedef SplitT<P> Split;
+    float amax = 0.0f;      // largest scaled value this lane sent through a clamp (P::kBounded policies)
     constexpr float kSx = P::kSx, kInvSx = 1.0f / P::kSx;
     const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
     if ((int64_t)blockIdx.x * 128 >= N) return;      // launches are sized for the worst case; uniform per workgroup
@@ -582,6 +513,9 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = (s * 8 + i) < 34 ? P::sym(src[s * 8 + i] * kSx) : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if ((s * 8 + i) < 34) P::watch_abs(amax, src[s * 8 + i] * kSx);
             bx[s] = split8t<P>(v);
         }
     }
@@ -655,13 +589,13 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     lds_bias<kOB>(acc, aux + Aux::kGeoL0B, h);
 #define BOPS_X(s) bx[s]
     OCC_LAYER_LDS8(kS_L0Geo, acc, BOPS_X)
-    relu_split(bact, acc);
+    relu_split<P>(bact, acc, amax);
 #define BOPS_ACT(s) bact[s]
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
         lds_bias<kOB>(acc, aux + Aux::kGeoHB + l * 256, h);
         OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
-        if (l < 2) relu_split(bact, acc);
+        if (l < 2) relu_split<P>(bact, acc, amax);
     }
     float sigma;
     {
@@ -678,7 +612,7 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         }
         sigma = (sacc + __shfl_xor(sacc, 32)) * kInvSx + aux[Aux::kSigma + 256];
     }
-    relu_split(bact, acc);
+    relu_split<P>(bact, acc, amax);
     // geometry head: 2 output blocks; a chunk carries 4 k-steps [step][hi|lo][ob][lane]
     f32x16 geo[2];
     lds_bias<2>(geo, aux + Aux::kGeoHeadB, h);
@@ -711,6 +645,8 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = P::sym(geo[b][sub * 8 + i]);
+#pragma unroll
+            for (int i = 0; i < 8; i++) P::watch_abs(amax, geo[b][sub * 8 + i]);
             bgeo[b * 2 + sub] = split8t<P>(v);
         }
     }
@@ -719,12 +655,12 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     lds_bias<kOB>(acc, aux + Aux::kRgbL0B, h);
 #define BOPS_RGB0(s) ((s) < 4 ? bgeo[(s) & 3] : bx[((s) - 4) < 0 ? 0 : ((s) - 4)])
     OCC_LAYER_LDS8(kS_L0Rgb, acc, BOPS_RGB0)
-    relu_split(bact, acc);
+    relu_split<P>(bact, acc, amax);
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
         lds_bias<kOB>(acc, aux + Aux::kRgbHB + l * 256, h);
         OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
-        if (l < 2) relu_split(bact, acc);
+        if (l < 2) relu_split<P>(bact, acc, amax);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the 3 tail chunks: nobody reads them
     float rgb[3];
@@ -750,6 +686,7 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         o[2] = rgb[2];
         o[3] = sigma;
     }
+    split_report<P>(amax, domain_flag);
 #undef BOPS_X
 #undef BOPS_ACT
 #undef BOPS_RGB0
@@ -831,7 +768,7 @@ static int mlp_bf16x3_launch(const float *mlp_in, const int32_t *in_rows, int64_
     const bf16x8 *pkh = reinterpret_cast<const bf16x8 *>(packed_bf16);
     if (variant == 0)
         hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<Bf16x3>), dim3((unsigned)blocks), dim3(256), 0,
-                           as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
+                           as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw, (uint32_t *)nullptr);
     else
         hipLaunchKernelGGL(canonical_mlp_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0,
                            as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
@@ -849,7 +786,8 @@ OCC_API int occnerf_canonical_mlp_bf16x3(const float *mlp_in, int64_t N, const f
 /* The fp32-grade split (F16x3 above): same packed fp32 blob for biases / head rows, weights from occnerf_canonical_mlp_pack_f16.
  * in_rows / n_dev nullable (all N_max rows, identity). */
 OCC_API int occnerf_canonical_mlp_f16x3(const float *mlp_in, const int32_t *in_rows, int64_t N_max, const int32_t *n_dev,
-                                        const float *packed, const void *packed_f16, float *raw, void *stream) {
+                                        const float *packed, const void *packed_f16, float *raw, uint32_t *domain_flag,
+                                        void *stream) {
     using namespace occ;
     if (N_max <= 0) return 0;
     OCC_REQUIRE(mlp_in && packed && packed_f16 && raw, "canonical_mlp_f16x3: null argument");
@@ -858,7 +796,8 @@ OCC_API int occnerf_canonical_mlp_f16x3(const float *mlp_in, const int32_t *in_r
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_f16x3: N too large");
     const f16x8 *pkh = reinterpret_cast<const f16x8 *>(packed_f16);
     const dim3 grid((unsigned)blocks), wg(256);
-    hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw);
+    hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw,
+                       domain_flag);
     return check_launch("canonical_mlp_f16x3");
 }
 

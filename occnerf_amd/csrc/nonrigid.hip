@@ -293,9 +293,10 @@ __global__ __launch_bounds__(256, 2) void nonrigid_split_kernel(const float *xyz
                                                                  const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/,
                                                                  const float *__restrict__ pk,
                                                                  const typename P::V8 *__restrict__ pkh, NrParams prm,
-                                                                 float *xyz_out) {
+                                                                 float *xyz_out, uint32_t *__restrict__ domain_flag /*nullable*/) {
     typedef typename P::V8 V8;
     typedef NrSplitT<P> NrSplit;
+    float amax = 0.0f;      // largest scaled value this lane sent through the ReLU clamp (split.h: P::kBounded policies)
     constexpr float kSx = P::kSx, kInvSx = 1.0f / P::kSx;
     __shared__ __attribute__((aligned(16))) V8 smem[kNrRing * kNrChunkUnits + NrAux::kTotal / 4];
     V8 *ring = smem;
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void nonrigid_split_kernel(const float *xyz
         _Pragma("unroll") for (int sub = 0; sub < 2; sub++) {                                      \
             float v[8];                                                                            \
             _Pragma("unroll") for (int i = 0; i < 8; i++) v[i] = P::relu(acc[ob][sub * 8 + i]);    \
+            _Pragma("unroll") for (int i = 0; i < 8; i += 2) P::watch(amax, acc[ob][sub * 8 + i], acc[ob][sub * 8 + i + 1]); \
             bact[ob * 2 + sub] = nr_split8<P>(v);                                                  \
         }                                                                                          \
     }
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(256, 2) void nonrigid_split_kernel(const float *xyz
 #pragma unroll
         for (int c = 0; c < 3; c++) xyz_out[nsrc * 3 + c] = __fadd_rn(p[c], off[c]);
     }
+    split_report<P>(amax, domain_flag);
 #undef NR_STEP
 #undef NR_BIAS
 #undef NR_RELU_SPLIT
@@ -509,7 +512,7 @@ static int nr_pack_split(const float *const *h_W, void *packed_split, void *stre
 template <typename P>
 static int nr_split_launch(const float *xyz_in, int64_t N_max, const int32_t *rows, const int32_t *n_dev, const float *cond,
                            const float *h_hann, const float *W0, const float *b0, float *packed, const void *packed_split,
-                           float *xyz_out, void *stream, const char *what) {
+                           float *xyz_out, uint32_t *domain_flag, void *stream, const char *what) {
     using namespace occ;
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(nr_fold_bias_kernel, dim3(1), dim3(128), 0, st, W0, b0, cond, packed + NrBlob::kL0B);
@@ -518,7 +521,7 @@ static int nr_split_launch(const float *xyz_in, int64_t N_max, const int32_t *ro
     const int64_t blocks = (N_max + 127) / 128;
     OCC_REQUIRE(blocks < (1ll << 31), "%s: N too large", what);
     hipLaunchKernelGGL(nonrigid_split_kernel<P>, dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N_max, rows, n_dev, packed,
-                       reinterpret_cast<const typename P::V8 *>(packed_split), prm, xyz_out);
+                       reinterpret_cast<const typename P::V8 *>(packed_split), prm, xyz_out, domain_flag);
     return check_launch(what);
 }
 
@@ -536,7 +539,7 @@ OCC_API int occnerf_nonrigid_bf16x3(const float *xyz_in, int64_t N, const float 
     if (N <= 0) return 0;
     OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && packed_bf16 && xyz_out,
                 "nonrigid_bf16x3: null argument");
-    return nr_split_launch<occ::Bf16x3>(xyz_in, N, nullptr, nullptr, cond, h_hann, W0, b0, packed, packed_bf16, xyz_out, stream,
+    return nr_split_launch<occ::Bf16x3>(xyz_in, N, nullptr, nullptr, cond, h_hann, W0, b0, packed, packed_bf16, xyz_out, nullptr, stream,
                                         "nonrigid_bf16x3");
 }
 
@@ -546,18 +549,18 @@ OCC_API int occnerf_nonrigid_bf16x3_rows(float *xyz, int64_t N_max, const int32_
     if (N_max <= 0) return 0;
     OCC_REQUIRE(xyz && rows && n_dev && cond && h_hann && W0 && b0 && packed && packed_bf16,
                 "nonrigid_bf16x3_rows: null argument");
-    return nr_split_launch<occ::Bf16x3>(xyz, N_max, rows, n_dev, cond, h_hann, W0, b0, packed, packed_bf16, xyz, stream,
+    return nr_split_launch<occ::Bf16x3>(xyz, N_max, rows, n_dev, cond, h_hann, W0, b0, packed, packed_bf16, xyz, nullptr, stream,
                                         "nonrigid_bf16x3_rows");
 }
 
 /* The fp32-grade split (split.h F16x3).  rows / n_dev nullable: all N_max samples; xyz_in may alias xyz_out. */
 OCC_API int occnerf_nonrigid_f16x3(const float *xyz_in, int64_t N_max, const int32_t *rows, const int32_t *n_dev,
                                    const float *cond, const float *h_hann, const float *W0, const float *b0, float *packed,
-                                   const void *packed_f16, float *xyz_out, void *stream) {
+                                   const void *packed_f16, float *xyz_out, uint32_t *domain_flag, void *stream) {
     if (N_max <= 0) return 0;
     OCC_REQUIRE(xyz_in && cond && h_hann && W0 && b0 && packed && packed_f16 && xyz_out, "nonrigid_f16x3: null argument");
     OCC_REQUIRE(!rows || n_dev, "nonrigid_f16x3: a row list needs its device-side count");
-    return nr_split_launch<occ::F16x3>(xyz_in, N_max, rows, n_dev, cond, h_hann, W0, b0, packed, packed_f16, xyz_out, stream,
+    return nr_split_launch<occ::F16x3>(xyz_in, N_max, rows, n_dev, cond, h_hann, W0, b0, packed, packed_f16, xyz_out, domain_flag, stream,
                                        "nonrigid_f16x3");
 }
 

@@ -44,6 +44,9 @@ struct Bf16x3 {
     static __device__ __forceinline__ V8 third(V8 xh) { return xh; }
     static __device__ __forceinline__ float relu(float a) { return fmaxf(a, 0.0f); }
     static __device__ __forceinline__ float sym(float a) { return a; }
+    static constexpr bool kBounded = false;                 // no saturation: nothing to report
+    static __device__ __forceinline__ void watch(float &, float, float) {}
+    static __device__ __forceinline__ void watch_abs(float &, float) {}
 };
 struct F16x3 {
     typedef f16x8 V8;
@@ -65,7 +68,23 @@ struct F16x3 {
     static __device__ __forceinline__ V8 third(V8 xh) { return xh * (E)0.00048828125f; }      // 2^-11
     static __device__ __forceinline__ float relu(float a) { return __builtin_amdgcn_fmed3f(a, 0.0f, 65504.0f); }
     static __device__ __forceinline__ float sym(float a) { return __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f); }
+    // Round 6: the clamps above are the edge of this mode's DOMAIN (scaled hidden activations below 65 504, i.e. activations
+    // below 4 094) and leaving it must not be silent: every value that goes through relu / sym also goes through a running
+    // per-lane maximum (one v_max3_f32 per two values); a wave whose maximum reached the bound sets the caller's flag word
+    // (split_report).  The host re-renders the frame with the fp32 kernels (Network.forward) -- see DESIGN.md section 3.
+    static constexpr bool kBounded = true;
+    static constexpr float kBound = 65504.0f;
+    static __device__ __forceinline__ void watch(float &m, float a, float b) { m = fmaxf(fmaxf(m, a), b); }
+    static __device__ __forceinline__ void watch_abs(float &m, float a) { m = fmaxf(m, fabsf(a)); }
 };
+
+// one atomic per wave that left the domain (none on the documented domain); flag may be NULL
+template <typename P>
+__device__ __forceinline__ void split_report(float amax, uint32_t *flag) {
+    if constexpr (P::kBounded) {
+        if (flag && __builtin_amdgcn_ballot_w64(amax >= P::kBound) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    }
+}
 
 
 }  // namespace occ

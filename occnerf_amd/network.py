@@ -197,6 +197,8 @@ class Network(nn.Module):
                                     [m.bias.detach() for m in nr_lin]),
             'nr_bf16': pack_n([m.weight.detach() for m in nr_lin]) if pack_n else None,
             'nr_w0': nr_lin[0].weight.detach(), 'nr_b0': nr_lin[0].bias.detach(),
+            # f16x3: the word its kernels set when a hidden activation reaches the mode's clamp (4 094; csrc/split.h)
+            'domain_flag': torch.zeros(1, device=cw[0].device, dtype=torch.int32) if prec == 'f16x3' else None,
         }
         return self._packed
 
@@ -261,7 +263,8 @@ class Network(nn.Module):
         frows, fcount, kmask = rows, count, mask
         if not cfg.ignore_non_rigid_motions:
             if pk['nr_bf16'] is not None:      # opt-in split-bf16 MFMA path (cfg.mlp_precision): same list, same count
-                ops.nonrigid_bf16x3_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'])
+                ops.nonrigid_bf16x3_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'],
+                                         domain_flag=pk['domain_flag'])
             else:
                 ops.nonrigid_rows(xyz, rows, count, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
         if dedup:       # (the positions before the offset differ in their last bits; after it they coincide)
@@ -293,7 +296,7 @@ class Network(nn.Module):
             self.last_head_counts = (fcount, mcount)
         return {'dedup': dedup, 'rays8': rays8, 'z': z, 'mask': mask, 'rows': rows, 'count': count, 'mlp_in': mlp_in,
                 'raw_c': raw_c, 'scan_a': scan_a, 'scan_b': scan_b, 'mrows': mrows, 'mcount': mcount, 'cnl': pk['cnl'],
-                'cnl_bf16': pk['cnl_bf16'], 'N': xyz.shape[0]}
+                'cnl_bf16': pk['cnl_bf16'], 'domain_flag': pk['domain_flag'], 'N': xyz.shape[0]}
 
     @staticmethod
     def _stage_mlp_composite(st, bgcolor, out, out_rows):
@@ -303,7 +306,8 @@ class Network(nn.Module):
 
         def mlp(raw_out, count, in_rows=None):
             if st['cnl_bf16'] is not None:          # opt-in split-bf16 MFMA path (cfg.mlp_precision)
-                ops.canonical_mlp_bf16x3(st['mlp_in'], st['cnl'], st['cnl_bf16'], raw_out, count=count, in_rows=in_rows)
+                ops.canonical_mlp_bf16x3(st['mlp_in'], st['cnl'], st['cnl_bf16'], raw_out, count=count, in_rows=in_rows,
+                                         domain_flag=st['domain_flag'])
             else:
                 ops.canonical_mlp(st['mlp_in'], st['cnl'], raw_out, count=count, in_rows=in_rows)
         if st['dedup']:
@@ -385,7 +389,7 @@ class Network(nn.Module):
         # every sample evaluated (cfg.skip_empty_samples off) and / or the brute-force neighbour search (cfg.knn_culling off)
         if not cfg.ignore_non_rigid_motions:
             if pk['nr_bf16'] is not None:
-                ops.nonrigid_bf16x3(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'], out=xyz)
+                ops.nonrigid_bf16x3(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], pk['nr_bf16'], out=xyz, domain_flag=pk['domain_flag'])
             else:
                 ops.nonrigid(xyz, cond, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], out=xyz)
         if cfg.get('knn_culling', True):     # same results, ~5x fewer distance evaluations
@@ -398,7 +402,7 @@ class Network(nn.Module):
             enc.embeddings.detach(), enc.offsets, enc.log2_per_level_scale, enc.base_resolution, pack=pack)
         del knn
         if pk['cnl_bf16'] is not None:          # opt-in split-bf16 MFMA path (cfg.mlp_precision)
-            ops.canonical_mlp_bf16x3(mlp_in, pk['cnl'], pk['cnl_bf16'], raw)
+            ops.canonical_mlp_bf16x3(mlp_in, pk['cnl'], pk['cnl_bf16'], raw, domain_flag=pk['domain_flag'])
         else:
             ops.canonical_mlp(mlp_in, pk['cnl'], raw)
         del mlp_in
@@ -532,14 +536,34 @@ class Network(nn.Module):
                             - torch.cuda.memory_allocated(dev))
                     cap = min(cap, max(1 << 22, int(free // 2 // 470)))
                 rays_per_pass = max(1, cap // S)
-                for i in range(0, R, rays_per_pass):
-                    n = min(rays_per_pass, R - i)
-                    if order is not None:
-                        self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                          wc['table'], out=out, out_rows=order[i:i + n], pack=pack, boxes=boxes, center=center)
-                    else:
-                        self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
-                                          wc['table'], out=tuple(t[i:i + n] for t in out), pack=pack, boxes=boxes, center=center)
+
+                def passes():
+                    for i in range(0, R, rays_per_pass):
+                        n = min(rays_per_pass, R - i)
+                        if order is not None:
+                            self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
+                                              wc['table'], out=out, out_rows=order[i:i + n], pack=pack, boxes=boxes, center=center)
+                        else:
+                            self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
+                                              wc['table'], out=tuple(t[i:i + n] for t in out), pack=pack, boxes=boxes, center=center)
+                passes()
+                # f16x3 is exact-grade only inside its domain (hidden activations below 4 094: csrc/split.h); its kernels
+                # report leaving it and the frame is then rendered again with the fp32 kernels -- never silently wrong pixels.
+                # (The read waits for the frame; cfg.f16x3_domain_check=False skips it and the guarantee.)
+                flag = self._packed_weights().get('domain_flag') if R > 0 else None
+                if flag is not None and cfg.get('f16x3_domain_check', True) and int(flag.item()) != 0:
+                    flag.zero_()
+                    self.f16x3_fallback_frames = getattr(self, 'f16x3_fallback_frames', 0) + 1
+                    if self.f16x3_fallback_frames == 1:
+                        import warnings
+                        warnings.warn("occnerf_amd: a hidden activation left the domain of cfg.mlp_precision='f16x3' (>= 4 094); "
+                                      'this frame -- and every later one that does -- is rendered again with the fp32 kernels')
+                    prec0 = cfg.mlp_precision
+                    cfg.mlp_precision = 'fp32'
+                    try:
+                        passes()
+                    finally:
+                        cfg.mlp_precision = prec0
                 rgb, acc, depth = out
                 comp_loss = torch.zeros(1, device=dev)
         else:

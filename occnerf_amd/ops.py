@@ -108,11 +108,9 @@ def _ptr_table(tensors, name):
 # ------------------------------------------------------------------ grid encoder (section 1)
 def _encoder_dtype(t, what):
     """gridencoder.cu:467,500 dispatch on the tensor dtype over float / double / half (grid.py:42-45 feeds half embeddings
-    under autocast).  float32 and float16 are built; float64 -- which nothing on this path produces -- is refused by name
-    instead of being silently converted."""
-    if t.dtype not in (torch.float32, torch.float16):
-        raise RuntimeError(f'{what}: tensors are {t.dtype}; this build implements the float32 and float16 dispatch cases of '
-                           f'gridencoder.cu:467 (float64 embeddings are not supported: cast with .float())')
+    under autocast): all three cases of AT_DISPATCH_FLOATING_TYPES_AND_HALF are built (csrc/grid_encode{,_f16,_f64}.hip)."""
+    if t.dtype not in (torch.float32, torch.float16, torch.float64):
+        raise RuntimeError(f'{what}: tensors are {t.dtype}; gridencoder.cu:467 dispatches float32, float64 and float16')
     return t.dtype
 
 
@@ -132,7 +130,13 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H,
     (bindings.cpp:6); writes `outputs[L,B,C]` (and `dy_dx`) in place.  Dispatches on embeddings.dtype like the reference."""
     dt = _encoder_dtype(embeddings, 'grid_encode_forward')
     with _guard(inputs):
-        if dt == torch.float16:
+        if dt == torch.float64:
+            rc = _lib.lib().occnerf_grid_encode_forward_f64(
+                _chk(inputs, torch.float32, 'inputs'), _chk(embeddings, torch.float64, 'embeddings'),
+                _chk(offsets, torch.int32, 'offsets'), _chk(outputs, torch.float64, 'outputs'),
+                int(B), int(D), int(Cc), int(L), float(S), int(H), _opt(dy_dx, torch.float64, 'dy_dx'),
+                int(gridtype), int(bool(align_corners)), int(interp), _stream(inputs))
+        elif dt == torch.float16:
             rc = _lib.lib().occnerf_grid_encode_forward_f16(
                 _chk(inputs, torch.float32, 'inputs'), _chk(embeddings, torch.float16, 'embeddings'),
                 _chk(offsets, torch.int32, 'offsets'), _chk(outputs, torch.float16, 'outputs'),
@@ -151,6 +155,16 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
                          dy_dx=None, grad_inputs=None, gridtype=0, align_corners=False, interp=0):
     """`_gridencoder.grid_encode_backward` (bindings.cpp:7); dispatches on grad.dtype like the reference (:500)."""
     dt = _encoder_dtype(grad, 'grid_encode_backward')
+    if dt == torch.float64:
+        with _guard(inputs):
+            rc = _lib.lib().occnerf_grid_encode_backward_f64(
+                _chk(grad, torch.float64, 'grad'), _chk(inputs, torch.float32, 'inputs'),
+                _chk(embeddings, torch.float64, 'embeddings'), _chk(offsets, torch.int32, 'offsets'),
+                _chk(grad_embeddings, torch.float64, 'grad_embeddings'), int(B), int(D), int(Cc), int(L), float(S), int(H),
+                _opt(dy_dx, torch.float64, 'dy_dx'), _opt(grad_inputs, torch.float64, 'grad_inputs'), int(gridtype),
+                int(bool(align_corners)), int(interp), _stream(inputs))
+        _lib.check(rc, 'grid_encode_backward')
+        return
     if dt == torch.float16:
         with _guard(inputs):
             rc = _lib.lib().occnerf_grid_encode_backward_f16(
@@ -409,7 +423,7 @@ def nonrigid_pack_f16(weights):
     return packed
 
 
-def _nonrigid_f16x3(xyz, rows, count, cond, hann, W0, b0, packed, packed_f16, out):
+def _nonrigid_f16x3(xyz, rows, count, cond, hann, W0, b0, packed, packed_f16, out, domain_flag=None):
     _kh, ph = _host_f32(hann, 6)
     n_max = xyz.shape[0] if rows is None else rows.shape[0]
     with _guard(xyz):
@@ -417,16 +431,17 @@ def _nonrigid_f16x3(xyz, rows, count, cond, hann, W0, b0, packed, packed_f16, ou
             _chk(xyz, torch.float32, 'xyz'), n_max, _opt(rows, torch.int32, 'rows'), _opt(count, torch.int32, 'count'),
             _chk(cond, torch.float32, 'cond'), ph, _chk(W0, torch.float32, 'W0'), _chk(b0, torch.float32, 'b0'),
             _chk(packed, torch.float32, 'packed'), _chk(packed_f16, torch.float16, 'packed_f16'),
-            _chk(out, torch.float32, 'xyz_out'), _stream(xyz))
+            _chk(out, torch.float32, 'xyz_out'), _opt(domain_flag, torch.int32, 'domain_flag'), _stream(xyz))
     _lib.check(rc, 'nonrigid_f16x3')
     return out
 
 
-def nonrigid_bf16x3(xyz, cond, hann, W0, b0, packed, packed_bf16, out=None):
-    """Split-operand non-rigid MLP; the dtype of the packed stream selects the split (bfloat16: bf16x3, float16: f16x3)."""
+def nonrigid_bf16x3(xyz, cond, hann, W0, b0, packed, packed_bf16, out=None, domain_flag=None):
+    """Split-operand non-rigid MLP; the dtype of the packed stream selects the split (bfloat16: bf16x3, float16: f16x3).
+    domain_flag (int32[1] on the device, f16x3 only): bit 0 is set when a hidden activation reached the mode's clamp (4 094)."""
     out = torch.empty_like(xyz) if out is None else out
     if packed_bf16.dtype == torch.float16:
-        return _nonrigid_f16x3(xyz, None, None, cond, hann, W0, b0, packed, packed_bf16, out)
+        return _nonrigid_f16x3(xyz, None, None, cond, hann, W0, b0, packed, packed_bf16, out, domain_flag)
     _kh, ph = _host_f32(hann, 6)
     with _guard(xyz):
         rc = _lib.lib().occnerf_nonrigid_bf16x3(
@@ -437,10 +452,10 @@ def nonrigid_bf16x3(xyz, cond, hann, W0, b0, packed, packed_bf16, out=None):
     return out
 
 
-def nonrigid_bf16x3_rows(xyz, rows, count, cond, hann, W0, b0, packed, packed_bf16):
+def nonrigid_bf16x3_rows(xyz, rows, count, cond, hann, W0, b0, packed, packed_bf16, domain_flag=None):
     """In place on the listed samples (the split-operand counterpart of nonrigid_rows): xyz[rows[i]] += offset, i < count[0]."""
     if packed_bf16.dtype == torch.float16:
-        return _nonrigid_f16x3(xyz, rows, count, cond, hann, W0, b0, packed, packed_bf16, xyz)
+        return _nonrigid_f16x3(xyz, rows, count, cond, hann, W0, b0, packed, packed_bf16, xyz, domain_flag)
     _kh, ph = _host_f32(hann, 6)
     with _guard(xyz):
         rc = _lib.lib().occnerf_nonrigid_bf16x3_rows(
@@ -688,17 +703,19 @@ def canonical_mlp_pack_f16(weights):
     return packed
 
 
-def canonical_mlp_bf16x3(mlp_in, packed, packed_bf16, raw, variant=0, count=None, in_rows=None):
+def canonical_mlp_bf16x3(mlp_in, packed, packed_bf16, raw, variant=0, count=None, in_rows=None, domain_flag=None):
     """Split-operand canonical MLP; the dtype of the packed stream selects the split (bfloat16: bf16x3, float16: f16x3).
     count (int32[1] on the device): entries to evaluate, read by the kernel (the launch covers the worst case);
-    in_rows (int32, optional): entry n takes input row in_rows[n]; results are compact (raw[n])."""
+    in_rows (int32, optional): entry n takes input row in_rows[n]; results are compact (raw[n]).
+    domain_flag (int32[1] on the device, f16x3 only): bit 0 is set when a value reached the mode's clamp (csrc/split.h)."""
     if packed_bf16.dtype == torch.float16:
         n_max = mlp_in.shape[0] if in_rows is None else in_rows.shape[0]
         with _guard(mlp_in):
             rc = _lib.lib().occnerf_canonical_mlp_f16x3(
                 _chk(mlp_in, torch.float32, 'mlp_in'), _opt(in_rows, torch.int32, 'in_rows'), n_max,
                 _opt(count, torch.int32, 'count'), _chk(packed, torch.float32, 'packed'),
-                _chk(packed_bf16, torch.float16, 'packed_f16'), _chk(raw, torch.float32, 'raw'), _stream(mlp_in))
+                _chk(packed_bf16, torch.float16, 'packed_f16'), _chk(raw, torch.float32, 'raw'),
+                _opt(domain_flag, torch.int32, 'domain_flag'), _stream(mlp_in))
         _lib.check(rc, 'canonical_mlp_f16x3')
         return raw
     with _guard(mlp_in):

@@ -226,6 +226,137 @@ OC_EXPORT void oc_grid_encode_backward(const float *grad, const float *inputs,
 }
 
 /* ------------------------------------------------------------------------- */
+/* a14/a19 with scalar_t = double (gridencoder.cu:467,500: the third dispatch case of AT_DISPATCH_FLOATING_TYPES_AND_HALF).
+ * inputs stay float (data_ptr<float>(), :470) and so do the cell position, the corner weight w and pos_deriv; embeddings,
+ * outputs, dy_dx and the gradients are double, every product with them is formed in double, and nvcc contracts
+ * `r += a * b` into one fma.                                                                                                */
+OC_EXPORT void oc_grid_encode_forward_f64(const float *inputs, const double *embeddings, const int32_t *offsets,
+                                          double *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                          uint32_t H, double *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp) {
+    float scale_l[32];
+    uint32_t res_l[32];
+    oc_grid_level_params(L, S, H, scale_l, res_l);
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        const float *x = inputs + (size_t)b * D;
+        int oob = 0;
+        for (uint32_t d = 0; d < D; d++)
+            if (x[d] < 0 || x[d] > 1) oob = 1;                                     /* :110-116 */
+        for (uint32_t level = 0; level < L; level++) {
+            double *out = outputs + ((size_t)level * B + b) * C;
+            double *dyl = dy_dx ? dy_dx + (((size_t)b * L + level) * D) * C : NULL;
+            if (oob) {                                                             /* :118-135 */
+                for (uint32_t ch = 0; ch < C; ch++) out[ch] = 0;
+                if (dyl) for (uint32_t i = 0; i < D * C; i++) dyl[i] = 0;
+                continue;
+            }
+            const double *grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+            const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+            const float scale = scale_l[level];
+            float pos[8], pos_deriv[8];
+            uint32_t pos_grid[8];
+            for (uint32_t d = 0; d < D; d++) {                                     /* :146-159, float */
+                pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) {
+                    pos_deriv[d] = 6 * pos[d] * (1.0f - pos[d]);
+                    pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+                } else {
+                    pos_deriv[d] = 1.0f;
+                }
+            }
+            double results[8] = {0};
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {                       /* :166-191 */
+                float w = 1;
+                uint32_t pl[8];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = oc_grid_index(D, C, gridtype, align_corners, hashmap_size, res_l[level], pl);
+                for (uint32_t ch = 0; ch < C; ch++) results[ch] = fma((double)w, grid[index + ch], results[ch]);
+            }
+            for (uint32_t ch = 0; ch < C; ch++) out[ch] = results[ch];
+            if (dyl) {                                                             /* :201-244 */
+                for (uint32_t gd = 0; gd < D; gd++) {
+                    double rg[8] = {0};
+                    for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                        float w = scale;
+                        uint32_t pl[8];
+                        for (uint32_t nd = 0; nd < D - 1; nd++) {
+                            const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                            if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                            else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+                        }
+                        pl[gd] = pos_grid[gd];
+                        const uint32_t il = oc_grid_index(D, C, gridtype, align_corners, hashmap_size, res_l[level], pl);
+                        pl[gd] = pos_grid[gd] + 1;
+                        const uint32_t ir = oc_grid_index(D, C, gridtype, align_corners, hashmap_size, res_l[level], pl);
+                        for (uint32_t ch = 0; ch < C; ch++) {
+                            const double t = (double)w * (grid[ir + ch] - grid[il + ch]);
+                            rg[ch] = fma(t, (double)pos_deriv[gd], rg[ch]);
+                        }
+                    }
+                    for (uint32_t ch = 0; ch < C; ch++) dyl[gd * C + ch] = rg[ch];
+                }
+            }
+        }
+    }
+}
+
+/* :248-369 with scalar_t = double; sums in (level, b, corner) order (the CUDA atomics' order is not defined: comparisons
+ * carry a float64 reordering tolerance). */
+OC_EXPORT void oc_grid_encode_backward_f64(const double *grad, const float *inputs, const int32_t *offsets,
+                                           double *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                           uint32_t H, const double *dy_dx, double *grad_inputs, uint32_t gridtype,
+                                           int align_corners, uint32_t interp) {
+    float scale_l[32];
+    uint32_t res_l[32];
+    oc_grid_level_params(L, S, H, scale_l, res_l);
+    for (uint32_t level = 0; level < L; level++) {
+        double *gg = grad_embeddings + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *x = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[8];
+            uint32_t pos_grid[8];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(x[d], scale_l[level], align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+            }
+            const double *g = grad + ((size_t)level * B + b) * C;
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+                uint32_t pl[8];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = oc_grid_index(D, C, gridtype, align_corners, hashmap_size, res_l[level], pl);
+                for (uint32_t ch = 0; ch < C; ch++) gg[index + ch] += (double)w * g[ch];
+            }
+        }
+    }
+    if (dy_dx && grad_inputs) {
+        for (uint32_t b = 0; b < B; b++)
+            for (uint32_t d = 0; d < D; d++) {
+                double r = 0;
+                for (uint32_t l = 0; l < L; l++)
+                    for (uint32_t ch = 0; ch < C; ch++)
+                        r = fma(grad[((size_t)l * B + b) * C + ch], dy_dx[(((size_t)b * L + l) * D + d) * C + ch], r);
+                grad_inputs[(size_t)b * D + d] = r;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* a14/a19 with scalar_t = at::Half (gridencoder.cu:467,500: the dispatch case grid.py:44-45 selects under
  * autocast).  c10::Half arithmetic (c10/util/Half-inl.h): every operator converts to float, computes, and
  * rounds the result to half (round-to-nearest-even); `Half += float` converts the float operand to Half first.

@@ -133,6 +133,36 @@ def grid_encode_backward(grad, inputs, offsets, n_emb, Cc, S, H, dy_dx=None, gri
     return ge, gi
 
 
+def grid_encode_forward_f64(inputs, embeddings, offsets, S, H, want_dy_dx=False, gridtype=0, align_corners=False, interp=0):
+    """gridencoder.cu:467's double dispatch case: float64 embeddings -> float64 outputs[L,B,C] (, dy_dx[B,L*D*C]); float inputs."""
+    inputs, embeddings, offsets = _f32(inputs), _f64(embeddings), _i32(offsets)
+    B, D = inputs.shape
+    Cc = embeddings.shape[1]
+    L = offsets.shape[0] - 1
+    out = np.empty((L, B, Cc), np.float64)
+    dy = np.empty((B, L * D * Cc), np.float64) if want_dy_dx else None
+    lib().oc_grid_encode_forward_f64(_p(inputs, _f32p), _p(embeddings, _f64p), _p(offsets, _i32p), _p(out, _f64p),
+                                     C.c_uint32(B), C.c_uint32(D), C.c_uint32(Cc), C.c_uint32(L), C.c_float(S),
+                                     C.c_uint32(H), _p(dy, _f64p), C.c_uint32(gridtype), C.c_int(int(align_corners)),
+                                     C.c_uint32(interp))
+    return out, dy
+
+
+def grid_encode_backward_f64(grad, inputs, offsets, n_emb, Cc, S, H, dy_dx=None, gridtype=0, align_corners=False, interp=0):
+    """float64 grad[L,B,C] -> float64 grad_embeddings[n_emb,C], grad_inputs[B,D] or None."""
+    grad, inputs, offsets = _f64(grad), _f32(inputs), _i32(offsets)
+    B, D = inputs.shape
+    L = offsets.shape[0] - 1
+    ge = np.zeros((n_emb, Cc), np.float64)
+    gi = np.zeros((B, D), np.float64) if dy_dx is not None else None
+    dy = _f64(dy_dx) if dy_dx is not None else None
+    lib().oc_grid_encode_backward_f64(_p(grad, _f64p), _p(inputs, _f32p), _p(offsets, _i32p), _p(ge, _f64p), C.c_uint32(B),
+                                      C.c_uint32(D), C.c_uint32(Cc), C.c_uint32(L), C.c_float(S), C.c_uint32(H),
+                                      _p(dy, _f64p), _p(gi, _f64p), C.c_uint32(gridtype), C.c_int(int(align_corners)),
+                                      C.c_uint32(interp))
+    return ge, gi
+
+
 _u16p = C.POINTER(C.c_uint16)
 
 

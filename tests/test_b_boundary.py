@@ -24,16 +24,19 @@ def test_ops_refuse_cpu_tensors(ops):
 
 
 def test_operator_seam_dtype_errors(ops):
-    """gridencoder.cu:467 dispatches float / double / half; this build implements float and half and refuses double by
-    name; mismatched tensors of a call are refused too."""
+    """gridencoder.cu:467 dispatches float / double / half and all three are built; tensors of a call whose dtypes do not match
+    are refused, as data_ptr<scalar_t>() would."""
     x = torch.rand(8, 4, device=DEV)
     off = torch.tensor([0, 64], dtype=torch.int32, device=DEV)
-    with pytest.raises(RuntimeError, match='float64'):
+    with pytest.raises(RuntimeError):                       # double embeddings need double outputs
         ops.grid_encode_forward(x, torch.zeros(64, 2, device=DEV, dtype=torch.float64), off, torch.zeros(1, 8, 2, device=DEV),
                                 8, 4, 2, 1, 1.0, 16)
-    with pytest.raises(RuntimeError, match='float64'):
+    with pytest.raises(RuntimeError):
         ops.grid_encode_backward(torch.zeros(1, 8, 2, device=DEV, dtype=torch.float64), x, torch.zeros(64, 2, device=DEV), off,
                                  torch.zeros(64, 2, device=DEV), 8, 4, 2, 1, 1.0, 16)
+    with pytest.raises(RuntimeError):                       # ... and integer tensors have no dispatch case
+        ops.grid_encode_forward(x, torch.zeros(64, 2, device=DEV, dtype=torch.int32), off, torch.zeros(1, 8, 2, device=DEV),
+                                8, 4, 2, 1, 1.0, 16)
     with pytest.raises(RuntimeError):                       # half embeddings need half outputs, as data_ptr<scalar_t>() insists
         ops.grid_encode_forward(x, torch.zeros(64, 2, device=DEV, dtype=torch.float16), off, torch.zeros(1, 8, 2, device=DEV),
                                 8, 4, 2, 1, 1.0, 16)
@@ -41,6 +44,41 @@ def test_operator_seam_dtype_errors(ops):
         h = torch.float16
         ops.grid_encode_backward(torch.zeros(1, 8, 1, device=DEV, dtype=h), x, torch.zeros(64, 1, device=DEV, dtype=h), off,
                                  torch.zeros(64, 1, device=DEV, dtype=h), 8, 4, 1, 1, 1.0, 16)
+
+
+@pytest.mark.parametrize('D,Cc,gridtype,interp,align', [(4, 2, 0, 0, False), (3, 4, 1, 1, True), (2, 1, 0, 0, False), (5, 8, 0, 0, False)])
+def test_grid_encode_double_dispatch(ops, oracle, D, Cc, gridtype, interp, align):
+    """gridencoder.cu:467,500 with scalar_t = double, through `_gridencoder` (the dtype of the embeddings / grad selects the case,
+    as AT_DISPATCH does): outputs and dy_dx BIT-EXACT against the oracle (same float cell arithmetic, one double fma per corner in
+    corner order); the backward's atomics reorder double sums: 1e-13 relative to the largest entry."""
+    import _gridencoder as _backend
+    from occnerf_amd.gridencoder import grid_offsets
+    rng = np.random.RandomState(D * 10 + Cc)
+    L, B = 6, 777
+    offs, pls = grid_offsets(D, L, 1.6, 4, 12, align_corners=align)
+    emb = rng.uniform(-1, 1, (int(offs[-1]), Cc))
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[0], x[1], x[2], x[4] = 0.0, 1.0, -1e-6, 0.5
+    x[3, -1] = 1.0 + 1e-6
+    S = np.log2(pls)
+    f64 = torch.float64
+    out = torch.empty(L, B, Cc, device=DEV, dtype=f64)
+    dy = torch.empty(B, L * D * Cc, device=DEV, dtype=f64)
+    _backend.grid_encode_forward(T(x), T(emb), T(offs), out, B, D, Cc, L, S, 4, dy, gridtype, align, interp)
+    want, want_dy = oracle.grid_encode_forward_f64(x, emb, offs, float(S), 4, True, gridtype, align, interp)
+    same(out.cpu().numpy(), want, 'float64 outputs')
+    same(dy.cpu().numpy(), want_dy, 'float64 dy_dx')
+    assert not out[:, 2].any() and not out[:, 3].any()
+    out2 = torch.empty(L, B, Cc, device=DEV, dtype=f64)
+    _backend.grid_encode_forward(T(x), T(emb), T(offs), out2, B, D, Cc, L, S, 4, None, gridtype, align, interp)
+    assert torch.equal(out, out2)
+    grad = rng.randn(L, B, Cc)
+    ge = torch.zeros(emb.shape, device=DEV, dtype=f64)
+    gi = torch.zeros(B, D, device=DEV, dtype=f64)
+    _backend.grid_encode_backward(T(grad), T(x), T(emb), T(offs), ge, B, D, Cc, L, S, 4, dy, gi, gridtype, align, interp)
+    wge, wgi = oracle.grid_encode_backward_f64(grad, x, offs, emb.shape[0], Cc, float(S), 4, want_dy, gridtype, align, interp)
+    assert np.abs(ge.cpu().numpy() - wge).max() <= 1e-13 * max(1.0, np.abs(wge).max())
+    same(gi.cpu().numpy(), wgi, 'float64 grad_inputs')            # (a fixed-order fma chain per (sample, dimension): exact)
 
 
 def test_grid_encoder_module_under_autocast(ops):

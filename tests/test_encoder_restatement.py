@@ -66,12 +66,15 @@ def grid_index(pos_grid, hashmap_size, resolution, gridtype, align_corners):
 
 
 def encode_numpy(x, emb, offsets, S, H, gridtype=0, align_corners=False, interp=0, contract_scale=True, contract_pos=True,
-                 contract_acc=True, exp2_ulps=0):
-    """-> outputs[L,B,C] float32 (gridencoder.cu:87-198)."""
-    x, emb = np.asarray(x, F32), np.asarray(emb, F32)
+                 contract_acc=True, exp2_ulps=0, acc_dtype=None):
+    """-> outputs[L,B,C] float32 (gridencoder.cu:87-198).  acc_dtype (e.g. np.longdouble): the scalar_t = double dispatch case
+    evaluated above its own precision -- cell position and corner weights in float32 as the template keeps them, the weighted
+    sum of the (float64) embeddings in acc_dtype."""
+    x = np.asarray(x, F32)
+    emb = np.asarray(emb, F32 if acc_dtype is None else np.float64)
     B, D = x.shape
     C, L = emb.shape[1], len(offsets) - 1
-    out = np.zeros((L, B, C), F32)
+    out = np.zeros((L, B, C), F32 if acc_dtype is None else acc_dtype)
     oob = ((x < 0) | (x > 1)).any(1)
     with np.errstate(over='ignore', invalid='ignore'):
         for level in range(L):
@@ -85,7 +88,7 @@ def encode_numpy(x, emb, offsets, S, H, gridtype=0, align_corners=False, interp=
             pos = (pos - pos_grid.astype(F32)).astype(F32)
             if interp == 1:
                 pos = (pos * pos * fma32(F32(-2.0), pos, F32(3.0))).astype(F32)      # (2 * val is exact: contraction or not)
-            res = np.zeros((B, C), F32)
+            res = np.zeros((B, C), F32 if acc_dtype is None else acc_dtype)
             for idx in range(1 << D):
                 w = np.ones(B, F32)
                 pl = pos_grid.copy()
@@ -98,6 +101,9 @@ def encode_numpy(x, emb, offsets, S, H, gridtype=0, align_corners=False, interp=
                 row = grid_index(pl, hashmap_size, resolution, gridtype, align_corners).astype(np.int64)
                 for ch in range(C):
                     v = grid[row, ch]
+                    if acc_dtype is not None:
+                        res[:, ch] = res[:, ch] + w.astype(acc_dtype) * v.astype(acc_dtype)
+                        continue
                     res[:, ch] = fma32(w, v, res[:, ch]) if contract_acc else (res[:, ch] + (w * v).astype(F32)).astype(F32)
             res[oob] = 0
             out[level] = res
@@ -142,6 +148,39 @@ def test_numpy_restatement_equals_the_c_oracle_generic(oracle, D, C, gridtype, i
     mine = encode_numpy(x, emb, offsets, S, 4, gridtype, align, interp)
     orc, _ = oracle.grid_encode_forward(x, emb, offsets, S, 4, False, gridtype, align, interp)
     assert np.array_equal(mine.view(np.uint32), orc.view(np.uint32))
+
+
+@pytest.mark.parametrize('D,C,gridtype,interp,align', [(4, 2, 0, 0, False), (3, 4, 1, 1, True), (2, 1, 0, 0, False)])
+def test_double_dispatch_case_of_the_c_oracle(oracle, D, C, gridtype, interp, align):
+    """gridencoder.cu:467 with scalar_t = double (round 6: the last dispatch case of the operator seam).  The C oracle's
+    restatement (float cell position and weights, double embeddings, one fma per corner) against this file's numpy evaluation
+    in extended precision: equal to a few ulps of float64; and with float32-representable embeddings it rounds to the float32
+    case's outputs within one float32 ulp.  Backward: the scatter is linear in grad -- checked against the forward's own
+    weights through <grad, forward(emb)> == <backward(grad), emb>."""
+    from occnerf_amd.gridencoder import grid_offsets
+    rng = np.random.RandomState(D * 100 + C)
+    L = 6
+    offsets, pls = grid_offsets(D, L, 1.7, 4, 11, align_corners=align)
+    emb = rng.uniform(-1, 1, (int(offsets[-1]), C))
+    x = rng.uniform(0, 1, (500, D)).astype(F32)
+    x[0], x[1], x[2] = 0.0, 1.0, -1e-6
+    S = float(np.log2(pls))
+    got, dy = oracle.grid_encode_forward_f64(x, emb, offsets, S, 4, True, gridtype, align, interp)
+    assert got.dtype == np.float64 and dy.dtype == np.float64 and not got[:, 2].any() and not dy[2].any()
+    want = encode_numpy(x, emb, offsets, S, 4, gridtype, align, interp, acc_dtype=np.longdouble)
+    assert np.abs(got - want.astype(np.float64)).max() <= 8 * np.finfo(np.float64).eps
+    emb32 = emb.astype(F32)
+    got32, _ = oracle.grid_encode_forward(x, emb32, offsets, S, 4, False, gridtype, align, interp)
+    got64, _ = oracle.grid_encode_forward_f64(x, emb32.astype(np.float64), offsets, S, 4, False, gridtype, align, interp)
+    assert np.abs(got64 - got32).max() <= 2 ** -22                                   # |values| < 2: a few float32 ulps of the sum
+    grad = rng.randn(L, len(x), C)
+    ge, gi = oracle.grid_encode_backward_f64(grad, x, offsets, emb.shape[0], C, S, 4, dy, gridtype, align, interp)
+    assert ge.dtype == np.float64 and gi.shape == x.shape
+    lhs, rhs = float((grad * got).sum()), float((ge * emb).sum())
+    assert abs(lhs - rhs) <= 1e-12 * max(1.0, abs(lhs))
+    # input gradient: grad_inputs[b, d] = sum_{l, c} grad[l, b, c] dy_dx[b, l, d, c]
+    want_gi = np.einsum('lbc,bldc->bd', grad, dy.reshape(len(x), L, D, C))
+    assert np.abs(gi - want_gi).max() <= 1e-12 * max(1.0, np.abs(want_gi).max())
 
 
 def test_uint32_wraparound_is_exercised(enc_case):

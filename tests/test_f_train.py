@@ -598,7 +598,6 @@ def test_per_step_hipgraph_matches_eager_and_is_captured_once():
     assert pg.captures == 3
 
 
-@pytest.mark.parametrize('amplify', [False, True])
 def test_per_step_hipgraph_survives_load_state_dict_and_two_forwards():
     """ADVICE r05.  (a) `load_state_dict` copies in place (no parameter pointer moves) but `invalidate_cache()` drops the
     device-side constants the captured graph baked the addresses of: the graphs are dropped with them, the next step captures
@@ -627,7 +626,8 @@ def test_per_step_hipgraph_survives_load_state_dict_and_two_forwards():
         net.train()
         nets[graph] = net
     net_g, net_e = nets[True], nets[False]
-    loss_of(net_g(**frames[0], iter_val=1e7)).backward()
+    for net in (net_g, net_e):        # (a training forward moves point_counter: both networks take the same steps)
+        loss_of(net(**frames[0], iter_val=1e7)).backward()
     pg0 = train_graph.get(net_g)
     assert pg0.captures == 1 and pg0.failed is None
     # (a)
@@ -655,6 +655,7 @@ def test_per_step_hipgraph_survives_load_state_dict_and_two_forwards():
     assert pg.replays == 3 and pg.eager_fallbacks == 1
 
 
+@pytest.mark.parametrize('amplify', [False, True])
 def test_fused_pose_chain_and_point_block_match_torch_autograd(amplify):
     """The two fused backward kernels of round 5 -- pose refiner -> Rodrigues -> forward kinematics -> inverse -> motion bases
     (csrc/preamble.hip pose_motion_bases_backward_kernel) and the per-point SDF block (csrc/features.hip

@@ -198,3 +198,49 @@ def test_bf16x3_render_uses_the_device_list(ops):
         net.cfg.skip_empty_samples, net.cfg.dedup_repeated_samples = True, True
     assert not calls
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+def test_f16x3_reports_leaving_its_domain():
+    """f16x3 clamps hidden activations at 4 094 (csrc/split.h) -- a checkpoint outside that domain must not
+    render wrong pixels silently.  (a) kernel level: inputs that push a first-layer activation past the clamp set the flag word,
+    inputs inside the domain leave it zero; (b) renderer: a checkpoint whose first canonical layer is scaled by 3e4 is detected,
+    the frame is rendered again by the fp32 kernels (bit-identical to an fp32 network's frame), a warning is issued once and the
+    counter moves; the unscaled checkpoint never falls back."""
+    import warnings
+    from occnerf_amd import ops
+    g = util.load_golden('freeview_amp_s32')
+    nr = bool(int(g['meta.non_rigid']))
+    data = frame_to_device(g, DEV)
+    # (a)
+    net, _ = build_network(int(g['meta.seed']), util.level(g), S=int(g['meta.S']), non_rigid=nr, mlp_precision='f16x3')
+    pk = net._packed_weights()
+    assert pk['domain_flag'] is not None and int(pk['domain_flag'].item()) == 0
+    x = torch.randn(1000, 68, device=DEV) * 0.3
+    raw = torch.zeros(1000, 5, device=DEV)
+    ops.canonical_mlp_bf16x3(x, pk['cnl'], pk['cnl_bf16'], raw, domain_flag=pk['domain_flag'])
+    assert int(pk['domain_flag'].item()) == 0
+    big = x.clone()
+    big[777, :34] = 5000.0                                  # 16 x 5000 > 65504: the input clamp itself
+    ops.canonical_mlp_bf16x3(big, pk['cnl'], pk['cnl_bf16'], raw, domain_flag=pk['domain_flag'])
+    assert int(pk['domain_flag'].item()) == 1
+    pk['domain_flag'].zero_()
+    # (b)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        with torch.no_grad():
+            net(**data, iter_val=1e7)                       # inside the domain: no warning, no fallback
+    assert getattr(net, 'f16x3_fallback_frames', 0) == 0
+    net32, _ = build_network(int(g['meta.seed']), util.level(g), S=int(g['meta.S']), non_rigid=nr)
+    for n in (net, net32):
+        with torch.no_grad():
+            n.cnl_mlp.module.pts_linears[0].weight.mul_(3e4)
+            n.cnl_mlp.module.pts_linears[0].bias.mul_(3e4)
+    with torch.no_grad():
+        want = net32(**data, iter_val=1e7)
+        with pytest.warns(UserWarning, match='f16x3'):
+            got = net(**data, iter_val=1e7)
+        got2 = net(**data, iter_val=1e7)                    # the second frame falls back too, without a second warning
+    assert net.f16x3_fallback_frames == 2
+    for k in ('rgb', 'alpha', 'depth'):
+        assert torch.equal(got[k], want[k]) and torch.equal(got2[k], want[k]), k
+    assert net.cfg.mlp_precision == 'f16x3'
