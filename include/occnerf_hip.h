@@ -535,6 +535,20 @@ int occnerf_linear_wgrad_reduce(const float *part, const float *dbpart, int32_t 
                                 const int32_t *row_map, const int32_t *col_map, float *dW, int32_t in_dim, float *db,
                                 int32_t accumulate, void *stream);
 
+/* The training step's forward of BOTH trunks in one launch (csrc/trunks.hip; occnerf_mlp.py:183-199, bf16 arithmetic with fp32
+ * accumulation -- BASELINE configs[4]): a sample's activations stay in registers through the ten layers (the renderer's
+ * transposed-MFMA scheme) and the tensors the backward reads are written on the way, row-major, exactly as the layer-by-layer
+ * forward (occnerf_linear_forward) produced them: X0[M,96] = [agg 35 | var | enc 32 | 0], A1..A4[M,256], GEO[M,96] (geometry
+ * features in columns 0..63, sigma in column 64), B1..B4[M,256], all bf16, and raw4[M,4] fp32 = (colour logits, sigma).
+ * h_W (host array of device pointers): the nine MFMA layers pts_linears.{0,2,4,6}, geo_linear.0, rgb_linears.{0,2,4,6} in torch
+ * layout; packed: occnerf_trunks_packed_bytes() bytes, zero-initialised once by the caller.  packed_f32: the blob of
+ * occnerf_canonical_mlp_pack (biases, sigma row, colour rows).  h_A / h_B: host arrays of the four activation buffers. */
+int64_t occnerf_trunks_packed_bytes(void);
+int occnerf_trunks_pack_bf16(const float *const *h_W, void *packed, void *stream);
+int occnerf_trunks_forward_bf16(const float *agg, const float *var, const float *enc, int64_t M, const float *packed_f32,
+                                const void *packed_bf16, void *X0, void *const *h_A, void *GEO, void *const *h_B, float *raw4,
+                                void *stream);
+
 /* Backward of occnerf_composite (network.py:320-348 under autograd): g_rgb[n,3], g_acc[n], g_depth[n] (each may
  * be NULL = zero) -> d_raw[n*S,5] (column 4 = 0) and d_mask[n*S] (optional).  S <= 256. */
 int occnerf_composite_backward(const float *raw, const float *mask, const float *z_vals, const float *rays,

@@ -36,6 +36,9 @@ SIGNATURES = {
                                                    _vp, _u32, C.c_int, _u32, _vp]),
     'occnerf_grid_encode_backward_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32,
                                                     _u32, _vp, _vp, _u32, C.c_int, _u32, _vp]),
+    'occnerf_trunks_packed_bytes': (_i64, []),
+    'occnerf_trunks_pack_bf16': (C.c_int, [_vp, _vp, _vp]),
+    'occnerf_trunks_forward_bf16': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'occnerf_grad_total_variation': (C.c_int, [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32,
                                                 _u32, _u32, C.c_int, _vp]),
     'occnerf_sample_warp': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,

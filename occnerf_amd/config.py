@@ -99,6 +99,7 @@ _DEFAULTS = {
     # split-bf16 MFMA, 16 bits per operand (meets the pixel gate on the random-init checkpoint only)
     'mlp_precision': 'fp32',
     'f16x3_domain_check': True,      # mlp_precision='f16x3': read the kernels' out-of-domain flag after the frame, re-render in fp32 when set
+    'train_fused_trunks': True,      # bf16 training step: the trunks' forward as one kernel (csrc/trunks.hip); False: ten layer passes
     'skip_empty_samples': True,      # drop samples whose motion-weight sum is exactly 0 (identical pixels)
     'device_rays': True,             # run.py: generate the frame's ray batch on the GPU (occnerf_amd/rays.py)
     'ray_patch_order': True,         # render rays in Morton-ordered pixel patches (any order is exact)

@@ -14,14 +14,19 @@
 //     ReLU and the rounding to bf16 that the staged forward applied when it stored them -- ARE the next layer's B operands
 //     (mlp_layout.h: register <-> feature map); same rounding points as the staged forward, different summation order.
 //   * weights: 2-byte stream [k-step][output block][lane] x 16 B, fetched once per 4-wave workgroup by LDS-DMA into a 4-slot
-//     ring of 8 KiB chunks (one 16-wide k-step of 8 output blocks), counted vmcnt + one raw s_barrier per chunk (mlp.hip).
+//     ring of 16 KiB chunks (two 16-wide k-steps of 8 output blocks), counted vmcnt + one raw s_barrier per chunk (mlp.hip).
 //   * saved activations leave through LDS: a wave writes its 32 x 128 tile in the accumulator layout (8 B per lane), reads it
 //     back row by row and stores 16 B per lane -- 4 rows x 256 contiguous bytes per instruction (linear.hip measured what the
-//     direct 8-byte scatter costs).  Stores and LDS-DMA share vmcnt and complete out of order with respect to each other, so
-//     the first chunk after a store phase waits for vmcnt(0); inside a layer only DMAs are in flight and the wait is counted.
+//     direct 8-byte scatter costs).  Stores and LDS-DMA share vmcnt and complete out of order with respect to each other:
+//     see OCC_ENTER for how the ring's depth keeps the stores off the critical path.
 //   * sigma and the three colour logits are VALU dot products over the fp32 accumulators with fp32 weights (as in the
 //     renderer's kernels) -- the staged forward took them from bf16 MFMA columns; both are bf16-grade evaluations of the same row.
-// Bound: bf16 MFMA issue ~ LDS operand reads (one ds_read_b128 per MFMA): 0.73 TFLOP per step.
+// One wave per SIMD (128 accumulators + 64 activation + 2 x 64 operand registers).  What bounds it (profiles/r06_trunks_forward.md,
+// diagnostic builds OCC_TRUNKS_EXP_*): 1.31 ms for 786 432 rows, of which 1.09 ms remain when nothing is saved -- 1 500 cycles
+// per 16-MFMA chunk against 512 of matrix time.  Halving the rendezvous count (two k-steps per chunk) and reading the operands
+// one chunk ahead changed nothing: the cost is the ISSUE of the LDS-DMA pieces, 4 per wave per chunk at 100-185 cycles each
+// (MI355X_MICROARCH.md) with one wave per SIMD and nothing to cover them -- a cost per KiB of weights, i.e. per 128 samples;
+// only more samples per workgroup (64 per wave: twice the accumulators) would amortise it further.
 #include "common.h"
 #include "mlp_layout.h"
 
@@ -33,21 +38,22 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kRing = 4;
-constexpr int kChunkUnits = 512;                                           // 16-byte units per chunk: 8 blocks x 64 lanes
-constexpr int kChunks = kS_L0Geo + 3 * kS_Hidden + kS_Hidden / 4 + kS_L0Rgb + 3 * kS_Hidden;      // 114
-constexpr int kTailChunks = kRing - 1;
+constexpr int kRing = 4;                                                   // chunks resident / in flight (see OCC_ENTER)
+constexpr int kChunkUnits = 1024;                                          // 16-byte units per chunk: 2 k-steps x 8 blocks x 64 lanes
+constexpr int kT_L0Geo = (kS_L0Geo + 1) / 2 * 2, kT_L0Rgb = (kS_L0Rgb + 1) / 2 * 2;      // k-steps padded to whole chunks: 6, 10
+constexpr int kChunks = kT_L0Geo / 2 + 3 * kS_Hidden / 2 + kS_Hidden / 8 + kT_L0Rgb / 2 + 3 * kS_Hidden / 2;      // 58
+constexpr int kTailChunks = kRing;                                         // zero chunks the prefetch may touch (one chunk is read ahead)
 constexpr int kStagePitch = 272;                                           // bytes per staged row: 128 features + 16 B pad
 constexpr int kStageBytes = 32 * kStagePitch;                              // per wave
 
 // stream offsets in chunks
 struct Stream {
     static constexpr int kGeoL0 = 0;
-    static constexpr int kGeoH = kGeoL0 + kS_L0Geo;
-    static constexpr int kGeoHead = kGeoH + 3 * kS_Hidden;
-    static constexpr int kRgbL0 = kGeoHead + kS_Hidden / 4;
-    static constexpr int kRgbH = kRgbL0 + kS_L0Rgb;
-    static constexpr int kTotal = kRgbH + 3 * kS_Hidden;
+    static constexpr int kGeoH = kGeoL0 + kT_L0Geo / 2;
+    static constexpr int kGeoHead = kGeoH + 3 * kS_Hidden / 2;
+    static constexpr int kRgbL0 = kGeoHead + kS_Hidden / 8;
+    static constexpr int kRgbH = kRgbL0 + kT_L0Rgb / 2;
+    static constexpr int kTotal = kRgbH + 3 * kS_Hidden / 2;
 };
 static_assert(Stream::kTotal == kChunks, "stream layout");
 
@@ -97,7 +103,7 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
-__global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(256, 1) void trunks_forward_kernel(const FwdArgs a) {
     // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read): [ring | stage x 4 waves | aux]
     __shared__ __attribute__((aligned(16))) bf16x8 smem[kRing * kChunkUnits + 4 * kStageBytes / 16 + Aux::kTotal / 4];
     bf16x8 *ring = smem;
@@ -122,9 +128,9 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
     copy(Aux::kOut, Blob::kOutW, 772);
 
     // ---- inputs: features h * 34 + t of [agg 35 | var | enc 32] -> the 5 k-steps of the first layer, and the bf16 row X0 ----
-    bf16x8 bx[kS_L0Geo];
+    bf16x8 bx[kT_L0Geo];
     {
-        float x[40];
+        float x[8 * kT_L0Geo];
         if (h == 0) {
 #pragma unroll
             for (int t = 0; t < 34; t++) x[t] = a.agg[ns * 35 + t];
@@ -135,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
             for (int t = 2; t < 34; t++) x[t] = a.enc[ns * 32 + (t - 2)];
         }
 #pragma unroll
-        for (int t = 34; t < 40; t++) x[t] = 0.0f;
+        for (int t = 34; t < 8 * kT_L0Geo; t++) x[t] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < kS_L0Geo; s++) {
+        for (int s = 0; s < kT_L0Geo; s++) {
 #pragma unroll
             for (int i = 0; i < 8; i++) bx[s][i] = (__bf16)x[s * 8 + i];
         }
@@ -156,47 +162,64 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
     // ---- weight stream: chunk g lives in ring slot g & 3; a wave fetches 2 of a chunk's 8 KiB ----
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) bf16x8 *)ring;
     auto issue_piece = [&](int g, int f) {
-        const int frag = wave * 2 + f;
+        const int frag = wave * 4 + f;
         glds16(a.pkh + (size_t)g * kChunkUnits + frag * 64, lane * 16,
                ring_lds + (unsigned)(((g & (kRing - 1)) * kChunkUnits + frag * 64) * 16));
     };
     int g = 0;                     // next chunk to consume
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        issue_piece(c, 0);
-        issue_piece(c, 1);
+    for (int c = 0; c < kRing; c++) {      // (one chunk is read ahead into registers: its slot refills a chunk later)
+#pragma unroll
+        for (int f = 0; f < 4; f++) issue_piece(c, f);
     }
-    bool after_stores = false;     // compile-time after unrolling: the next chunk wait must drain vmcnt (see the header)
+    // Stores and LDS-DMA share vmcnt and retire out of order with respect to each other, so a counted wait is only meaningful
+    // while DMAs alone are in flight.  A store phase therefore BEGINS with vmcnt(0) -- the 3 chunks ahead are in LDS (they were
+    // issued 2-6 k-steps ago) -- and the next 3 chunk entries need no wait at all; by the 4th, whose DMA was issued after the
+    // stores, 6 k-steps (~3 K cycles) have passed and the stores have retired: the counted wait resumes without a stall.
+    int landed = 0;                // chunks ahead known to be in LDS (set by a store phase)
 
-    // enter chunk g: this wave's pieces of it have landed, rendezvous, slot of chunk g - 1 is free for chunk g + 3
+    // enter chunk g (to READ it ahead, while chunk g - 1 is multiplied): this wave's pieces of it have landed, rendezvous --
+    // every wave holds chunk g - 1 in registers by then, so its slot is free for chunk g + 3
 #define OCC_ENTER()                                                                    \
-    if (after_stores) {                                                                \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               \
-        after_stores = false;                                                          \
+    if (landed > 0) {                                                                  \
+        landed--;                                                                      \
     } else {                                                                           \
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                               \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                               \
     }                                                                                  \
     __builtin_amdgcn_s_barrier();                                                      \
     const bf16x8 *slot_ = ring + (g & (kRing - 1)) * kChunkUnits;                      \
     g++;
 #define OCC_REFILL(F)                                   \
     __builtin_amdgcn_sched_barrier(0);                  \
-    issue_piece(g + 2, F);                              \
+    issue_piece(g + (kRing - 2), F);                    \
     __builtin_amdgcn_sched_barrier(0);
+#define OCC_STORE_PHASE()                               \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    \
+    landed = kRing - 1;
 #define OCC_MMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A_), (B_), (C_), 0, 0, 0)
 
-    // one 16-wide k-step per chunk, 8 output blocks; the refill's two DMA pieces go out between the MFMAs
+    // Two 16-wide k-steps per chunk, 8 output blocks.  The 16 operand fragments of the NEXT chunk are read while the current
+    // chunk's 16 MFMAs run: right behind the chunk barrier all four waves would otherwise read (4 x 16 KiB through a 128 B/clk
+    // LDS = 512 cycles) and only then multiply (512 cycles) -- measured 1 500 cycles per chunk, profiles/r06_trunks_forward.md.
+    // A chunk is 16 fragments x 64 lanes x 16 B whatever the layer: [k-step][block] here, [k-step][2 blocks] x 8 in the head.
+    bf16x8 W[16];
+#define OCC_NEXT(DST)                                                                      \
+    OCC_ENTER()                                                                            \
+    _Pragma("unroll") for (int f_ = 0; f_ < 16; f_++) DST[f_] = slot_[f_ * 64 + lane];
 #define OCC_LAYER8(STEPS, ACC, BOPS)                                                       \
-    _Pragma("unroll") for (int s_ = 0; s_ < (STEPS); s_++) {                               \
-        OCC_ENTER()                                                                        \
-        bf16x8 w_[4], v_[4];                                                               \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) w_[ob_] = slot_[ob_ * 64 + lane]; \
-        const bf16x8 b_ = BOPS(s_);                                                        \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) v_[ob_] = slot_[(4 + ob_) * 64 + lane]; \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) ACC[ob_] = OCC_MMA(w_[ob_], b_, ACC[ob_]); \
+    _Pragma("unroll") for (int s_ = 0; s_ < (STEPS); s_ += 2) {                            \
+        bf16x8 nw_[16];                                                                    \
+        OCC_NEXT(nw_)                                                                      \
+        const bf16x8 b0_ = BOPS(s_), b1_ = BOPS(s_ + 1);                                   \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) ACC[ob_] = OCC_MMA(W[ob_], b0_, ACC[ob_]); \
         OCC_REFILL(0)                                                                      \
-        _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) ACC[4 + ob_] = OCC_MMA(v_[ob_], b_, ACC[4 + ob_]); \
+        _Pragma("unroll") for (int ob_ = 4; ob_ < kOB; ob_++) ACC[ob_] = OCC_MMA(W[ob_], b0_, ACC[ob_]); \
         OCC_REFILL(1)                                                                      \
+        _Pragma("unroll") for (int ob_ = 0; ob_ < 4; ob_++) ACC[ob_] = OCC_MMA(W[kOB + ob_], b1_, ACC[ob_]); \
+        OCC_REFILL(2)                                                                      \
+        _Pragma("unroll") for (int ob_ = 4; ob_ < kOB; ob_++) ACC[ob_] = OCC_MMA(W[kOB + ob_], b1_, ACC[ob_]); \
+        OCC_REFILL(3)                                                                      \
+        _Pragma("unroll") for (int f_ = 0; f_ < 16; f_++) W[f_] = nw_[f_];                 \
     }
 
     auto bias = [&](f32x16 (&acc_)[kOB], const float *src) {
@@ -221,6 +244,9 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
                 for (int i = 0; i < 8; i++) b[ob * 2 + sub][i] = (__bf16)fmaxf(acc_[ob][sub * 8 + i], 0.0f);
             }
         }
+#ifdef OCC_TRUNKS_EXP_NO_SAVE      // (tools/trunks_phases.py: what the kernel costs without writing the activations)
+        return;
+#endif
 #pragma unroll
         for (int half = 0; half < 2; half++) {            // 128 features at a time
 #pragma unroll
@@ -235,24 +261,29 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's own tile: no barrier needed
+            if (half == 0) { OCC_STORE_PHASE() }                        // (as late as possible: the newest DMA is one k-step old)
 #pragma unroll
             for (int it = 0; it < 8; it++) {
                 const int r = it * 4 + (lane >> 4), c = lane & 15;
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + r * kStagePitch + c * 16);
+#ifdef OCC_TRUNKS_EXP_NO_STORE     // (tools/trunks_phases.py: staging through LDS, no global store)
+                if (v[0] == 0x12345678u && m0 + r < a.M) *reinterpret_cast<u32x4 *>(dst + (m0 + r) * 256 + half * 128 + c * 8) = v;
+#else
                 if (m0 + r < a.M) *reinterpret_cast<u32x4 *>(dst + (m0 + r) * 256 + half * 128 + c * 8) = v;
+#endif
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // tile read before the next half overwrites it
         }
-        after_stores = true;
     };
 
     f32x16 acc[kOB];
     bf16x8 bact[2 * kOB];
+    OCC_NEXT(W)                    // chunk 0
 
     // ---------------- geometry trunk ----------------
     bias(acc, aux + Aux::kGeoL0B);
 #define BOPS_X(s) bx[s]
-    OCC_LAYER8(kS_L0Geo, acc, BOPS_X)
+    OCC_LAYER8(kT_L0Geo, acc, BOPS_X)
     relu_keep(bact, acc, a.A[0]);
 #define BOPS_ACT(s) bact[s]
 #pragma unroll 1
@@ -277,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
         }
         sigma = (sacc + __shfl_xor(sacc, 32)) + aux[Aux::kSigma + 256];
     }
-    // geometry head: 2 output blocks; a chunk carries 4 k-steps [step][ob][lane]
+    // geometry head: 2 output blocks; a chunk carries 8 k-steps [step][ob][lane]
     f32x16 geo[2];
     {
         const f32x4 *B4 = reinterpret_cast<const f32x4 *>(aux + Aux::kGeoHeadB);
@@ -292,16 +323,21 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
         }
     }
 #pragma unroll
-    for (int c = 0; c < kS_Hidden / 4; c++) {
-        OCC_ENTER()
+    for (int c = 0; c < kS_Hidden / 8; c++) {
+        bf16x8 nw[16];
+        OCC_NEXT(nw)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const bf16x8 b = bact[c * 4 + q];
+        for (int q = 0; q < 8; q++) {
+            const bf16x8 b = bact[c * 8 + q];
 #pragma unroll
-            for (int ob = 0; ob < 2; ob++) geo[ob] = OCC_MMA(slot_[(q * 2 + ob) * 64 + lane], b, geo[ob]);
+            for (int ob = 0; ob < 2; ob++) geo[ob] = OCC_MMA(W[q * 2 + ob], b, geo[ob]);
             if (q == 1) { OCC_REFILL(0) }
             if (q == 3) { OCC_REFILL(1) }
+            if (q == 5) { OCC_REFILL(2) }
+            if (q == 7) { OCC_REFILL(3) }
         }
+#pragma unroll
+        for (int f = 0; f < 16; f++) W[f] = nw[f];
     }
     bf16x8 bgeo[4];          // 64 geometry features (no activation) as 4 k-steps
 #pragma unroll
@@ -312,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
             for (int i = 0; i < 8; i++) bgeo[b * 2 + sub][i] = (__bf16)geo[b][sub * 8 + i];
         }
     }
+    OCC_STORE_PHASE()
     if (n < a.M) {           // GEO row: 64 features (8-byte pieces), sigma + zeros; raw4 later with the colour logits
         __bf16 *grow = a.GEO + n * 96;
 #pragma unroll
@@ -329,22 +366,22 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
         tail[0] = t0;
         tail[1] = u32x4{0u, 0u, 0u, 0u};
     }
-    after_stores = true;
 
     // ---------------- colour trunk ----------------
     // (the input row again, from the bf16 copy this lane stored at the top: 20 registers not carried through the geometry trunk)
     {
         const uint32_t *row = reinterpret_cast<const uint32_t *>(a.X0 + ns * 96 + h * 34);
-        uint32_t xw[20];
+        uint32_t xw[4 * kT_L0Geo];
 #pragma unroll
         for (int t = 0; t < 17; t++) xw[t] = n < a.M ? row[t] : 0u;
-        xw[17] = xw[18] = xw[19] = 0u;
 #pragma unroll
-        for (int s = 0; s < kS_L0Geo; s++) bx[s] = __builtin_bit_cast(bf16x8, u32x4{xw[4 * s], xw[4 * s + 1], xw[4 * s + 2], xw[4 * s + 3]});
+        for (int t = 17; t < 4 * kT_L0Geo; t++) xw[t] = 0u;
+#pragma unroll
+        for (int s = 0; s < kT_L0Geo; s++) bx[s] = __builtin_bit_cast(bf16x8, u32x4{xw[4 * s], xw[4 * s + 1], xw[4 * s + 2], xw[4 * s + 3]});
     }
     bias(acc, aux + Aux::kRgbL0B);
-#define BOPS_RGB0(s) ((s) < 4 ? bgeo[(s) & 3] : bx[((s) - 4) < 0 ? 0 : ((s) - 4)])
-    OCC_LAYER8(kS_L0Rgb, acc, BOPS_RGB0)
+#define BOPS_RGB0(s) ((s) < 4 ? bgeo[(s) & 3] : bx[((s) - 4) < 0 ? 0 : ((s) - 4) >= kT_L0Geo ? kT_L0Geo - 1 : ((s) - 4)])
+    OCC_LAYER8(kT_L0Rgb, acc, BOPS_RGB0)
     relu_keep(bact, acc, a.B[0]);
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
@@ -374,8 +411,10 @@ __global__ __launch_bounds__(256, 2) void trunks_forward_kernel(const FwdArgs a)
 #undef BOPS_ACT
 #undef BOPS_RGB0
 #undef OCC_LAYER8
+#undef OCC_NEXT
 #undef OCC_MMA
 #undef OCC_REFILL
+#undef OCC_STORE_PHASE
 #undef OCC_ENTER
 }
 
@@ -400,11 +439,11 @@ OCC_API int occnerf_trunks_pack_bf16(const float *const *h_W, void *packed, void
         hipLaunchKernelGGL(trunks::pack_layer_kernel, dim3(128), dim3(256), 0, st, h_W[li], kind, in_dim, out_dim, steps, ob,
                            base + (size_t)chunk * kChunkUnits * 8);
     };
-    layer(0, kL0Geo, kInGeo, kWidth, kS_L0Geo, kOB, Stream::kGeoL0);
-    for (int l = 0; l < 3; l++) layer(1 + l, kHidden, kWidth, kWidth, kS_Hidden, kOB, Stream::kGeoH + l * kS_Hidden);
+    layer(0, kL0Geo, kInGeo, kWidth, kT_L0Geo, kOB, Stream::kGeoL0);
+    for (int l = 0; l < 3; l++) layer(1 + l, kHidden, kWidth, kWidth, kS_Hidden, kOB, Stream::kGeoH + l * kS_Hidden / 2);
     layer(4, kGeoHead, kWidth, 65, kS_Hidden, 2, Stream::kGeoHead);
-    layer(5, kL0Rgb, kInRgb, kWidth, kS_L0Rgb, kOB, Stream::kRgbL0);
-    for (int l = 0; l < 3; l++) layer(6 + l, kHidden, kWidth, kWidth, kS_Hidden, kOB, Stream::kRgbH + l * kS_Hidden);
+    layer(5, kL0Rgb, kInRgb, kWidth, kT_L0Rgb, kOB, Stream::kRgbL0);
+    for (int l = 0; l < 3; l++) layer(6 + l, kHidden, kWidth, kWidth, kS_Hidden, kOB, Stream::kRgbH + l * kS_Hidden / 2);
     return check_launch("trunks_pack_bf16");
 }
 

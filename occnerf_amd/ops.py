@@ -679,6 +679,37 @@ def canonical_mlp(mlp_in, packed, raw, direct=False, count=None, in_rows=None):
     return raw
 
 
+def trunks_pack_bf16(weights, out=None):
+    """Plain-bf16 operand stream of the nine MFMA layers for the training step's fused forward (csrc/trunks.hip)."""
+    dev = weights[0].device
+    if out is None:
+        out = torch.zeros(_lib.lib().occnerf_trunks_packed_bytes() // 2, device=dev, dtype=torch.bfloat16)
+    with _guard_dev(dev):
+        rc = _lib.lib().occnerf_trunks_pack_bf16(_ptr_table(weights[:9], 'W'), out.data_ptr(), _stream(out))
+    _lib.check(rc, 'trunks_pack_bf16')
+    return out
+
+
+def trunks_forward_bf16(agg, var, enc, packed_f32, packed_bf16):
+    """Both trunks forward in one kernel, the activations the backward needs written on the way (csrc/trunks.hip).
+    -> X0[M,96], [A1..A4][M,256], GEO[M,96], [B1..B4][M,256] (bf16, row-major), raw4[M,4] fp32."""
+    M, dev, bf = agg.shape[0], agg.device, torch.bfloat16
+    X0 = torch.empty(M, 96, device=dev, dtype=bf)
+    A = [torch.empty(M, 256, device=dev, dtype=bf) for _ in range(4)]
+    GEO = torch.empty(M, 96, device=dev, dtype=bf)
+    B = [torch.empty(M, 256, device=dev, dtype=bf) for _ in range(4)]
+    raw4 = torch.empty(M, 4, device=dev, dtype=torch.float32)
+    pa = (C.c_void_p * 4)(*[t.data_ptr() for t in A])
+    pb = (C.c_void_p * 4)(*[t.data_ptr() for t in B])
+    with _guard(agg):
+        rc = _lib.lib().occnerf_trunks_forward_bf16(
+            _chk(agg, torch.float32, 'agg'), _chk(var, torch.float32, 'var'), _chk(enc, torch.float32, 'enc'), M,
+            _chk(packed_f32, torch.float32, 'packed_f32'), _chk(packed_bf16, torch.bfloat16, 'packed_bf16'), X0.data_ptr(), pa,
+            GEO.data_ptr(), pb, raw4.data_ptr(), _stream(agg))
+    _lib.check(rc, 'trunks_forward_bf16')
+    return X0, A, GEO, B, raw4
+
+
 def canonical_mlp_pack_bf16(weights):
     """hi/lo bf16 split of the 10 weight matrices in bf16-MFMA operand order."""
     dev = weights[0].device

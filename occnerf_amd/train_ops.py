@@ -152,12 +152,24 @@ class _Trunks(Function):
     """
 
     @staticmethod
-    def forward(ctx, agg, var, enc, bf16, *wb):
+    def forward(ctx, agg, var, enc, bf16, fused, packed_f32, *wb):
         W, b = wb[:10], wb[10:]
         dev, M, dt = agg.device, agg.shape[0], _dtype(bf16)
         maps = _trunk_maps(dev)
         packs = [linear_pack(W[l].detach().float().contiguous(), b[l].detach().float().contiguous(),
                              maps['rows'][l], maps['cols'][l], bf16) for l in range(10)]
+        if bf16 and fused:
+            # one kernel for the ten layers, saved activations written on the way (csrc/trunks.hip): same tensors, same layout
+            Wf = [w.detach().float().contiguous() for w in W]
+            blob = packed_f32 if packed_f32 is not None else ops.canonical_mlp_pack(Wf, [x.detach().float().contiguous() for x in b])
+            X0, A, GEO, B, raw4 = ops.trunks_forward_bf16(agg.contiguous(), var.contiguous(), enc.contiguous(), blob,
+                                                          ops.trunks_pack_bf16(Wf))
+            ctx.bf16 = bf16
+            ctx.acts, ctx.GEO, ctx.B = [X0] + A, GEO, B
+            ctx.Wt = [p[1] for p in packs]
+            ctx.shapes = [tuple(w.shape) for w in W]
+            ctx.needs = [w.requires_grad for w in W]
+            return raw4
         X0 = torch.zeros(M, 96, device=dev, dtype=dt)
         X0[:, :35] = agg
         X0[:, 35:36] = var
@@ -217,17 +229,19 @@ class _Trunks(Function):
         dx0 = linear_forward(dz_rgb0, 256, torch.cat([Wt[5][96:], Wt[0]], dim=1).contiguous(), 96, bf16, x1=dz, k1=256,
                              out_f32=True)
         ctx.acts = ctx.GEO = ctx.B = ctx.Wt = None
-        return (dx0[:, :35], None, dx0[:, 36:68], None) + tuple(dW) + tuple(db)
+        return (dx0[:, :35], None, dx0[:, 36:68], None, None, None) + tuple(dW) + tuple(db)
 
 
-def canonical_trunks(cm, agg, var, enc, bf16):
-    """cm: CanonicalMLP (its ten Linear layers are the parameters); -> raw4[M,4] fp32."""
+def canonical_trunks(cm, agg, var, enc, bf16, fused=True, packed_f32=None):
+    """cm: CanonicalMLP (its ten Linear layers are the parameters); -> raw4[M,4] fp32.
+    fused (bf16 only): the forward as ONE kernel that writes the saved activations on the way (csrc/trunks.hip) instead of
+    ten layer passes; packed_f32: the caller's current blob of ops.canonical_mlp_pack (biases, head rows), packed here if None."""
     import torch.nn as nn
     mods = [m for m in cm.pts_linears if isinstance(m, nn.Linear)] + [cm.geo_linear[0]] + \
            [m for m in cm.rgb_linears if isinstance(m, nn.Linear)] + [cm.output_linear[0]]
     if cm.mlp_depth != 4 or cm.mlp_width != 256:
         raise RuntimeError('the HIP training trunks are built for mlp_depth=4, mlp_width=256')
-    return _Trunks.apply(agg.float(), var.float(), enc.float(), bool(bf16),
+    return _Trunks.apply(agg.float(), var.float(), enc.float(), bool(bf16), bool(fused), packed_f32,
                          *[m.weight for m in mods], *[m.bias for m in mods])
 
 

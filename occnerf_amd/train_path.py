@@ -265,7 +265,8 @@ def canonical_mlp_hip(cm, xyz, knn_idxs, net, knn_base, point_sdf, ctx, bf16):
         feats = enc(torch.cat((pc01, sdf01), dim=-1).float(), bound=None)
         feats = torch.cat((feats, pc), dim=-1)                                       # [P,35]
         agg = ops.aggregate(feats, knn40, atts)
-        raw4 = train_ops.canonical_trunks(cm, agg, var, h, bf16)
+        raw4 = train_ops.canonical_trunks(cm, agg, var, h, bf16, fused=bool(net.cfg.get('train_fused_trunks', True)),
+                                          packed_f32=net._packed_weights()['cnl'] if bf16 else None)
     return torch.cat((raw4, dist), dim=-1)
 
 

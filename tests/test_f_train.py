@@ -204,6 +204,56 @@ def test_trunks_forward_backward(bf16):
             assert rel <= 2e-5, (k, rel, omc)
 
 
+def test_fused_trunk_forward_writes_what_the_layer_passes_wrote():
+    """Round 6: the bf16 forward of both trunks as ONE kernel (csrc/trunks.hip) against the ten layer passes it replaces
+    (csrc/linear.hip), ragged M.  Same operands, same rounding points (every stored activation is bf16), another summation
+    order: the saved activations -- X0, A1..A4, GEO, B1..B4, the backward's inputs -- agree to a bf16 ulp of the row's scale
+    wherever no ReLU unit flipped, raw4 to bf16 grade, and the gradients of a backward through either agree (cosine)."""
+    from occnerf_amd import train_ops as to
+    net, _ = build_network(0, True, S=32, non_rigid=False)
+    cm = net.cnl_mlp.module
+    g = torch.Generator(device='cpu').manual_seed(5)
+    M = 4099 + 128 * 3 + 17
+    agg0 = torch.randn(M, 35, generator=g).to(DEV)
+    var = torch.rand(M, 1, generator=g).to(DEV)
+    enc0 = torch.randn(M, 32, generator=g).to(DEV)
+    gout = torch.randn(M, 4, generator=g).to(DEV)
+    saved, grads, raws = {}, {}, {}
+    real = to._Trunks.backward
+    for fused in (False, True):
+        agg, enc = agg0.clone().requires_grad_(True), enc0.clone().requires_grad_(True)
+
+        def spy(ctx, d, tag=fused):
+            saved[tag] = [t.clone() for t in ctx.acts] + [ctx.GEO.clone()] + [t.clone() for t in ctx.B]
+            return real(ctx, d)
+        to._Trunks.backward = staticmethod(spy)
+        try:
+            raw = to.canonical_trunks(cm, agg, var, enc, True, fused=fused)
+            (raw * gout).sum().backward()
+        finally:
+            to._Trunks.backward = real
+        raws[fused] = raw.detach()
+        grads[fused] = {'agg': agg.grad.clone(), 'enc': enc.grad.clone(), **{n: p.grad.clone() for n, p in cm.named_parameters()
+                                                                           if p.grad is not None}}
+        cm.zero_grad(set_to_none=True)
+    names = ['X0', 'A1', 'A2', 'A3', 'A4', 'GEO', 'B1', 'B2', 'B3', 'B4']
+    assert [t.shape for t in saved[True]] == [t.shape for t in saved[False]]
+    assert all(t.dtype == torch.bfloat16 for t in saved[True])
+    assert torch.equal(saved[True][0], saved[False][0])                       # X0: the same rounding of the same inputs
+    for nm, a, b in zip(names[1:], saved[True][1:], saved[False][1:]):
+        a, b = a.float(), b.float()
+        scale = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-6)
+        err = ((a - b).abs() / scale)
+        # a bf16 ulp is 2^-8 of the value; deeper layers see inputs that already differ by an ulp here and there
+        assert float(err.mean()) <= 2e-3 and float((err > 2.0 ** -6).float().mean()) <= 2e-3, (nm, float(err.mean()), float(err.max()))
+    assert float((saved[True][5][:, 65:].float().abs().max())) == 0.0                # GEO pad columns
+    r1, r0 = raws[True], raws[False]
+    assert float((r1 - r0).abs().max()) <= 3e-2 * float(r0.abs().max())
+    assert float(_cos(r1, r0)) >= 1 - 1e-4
+    for k in grads[False]:
+        assert 1 - _cos(grads[True][k], grads[False][k]) <= 2e-4, k
+
+
 # ------------------------------------------------------------------------------------------ compositing
 @pytest.mark.parametrize('S', [2, 63, 64, 65, 128, 192, 256])
 def test_composite_backward(S):
@@ -485,9 +535,9 @@ def test_autocast_selects_bf16_trunks():
     seen = []
     real = train_ops.canonical_trunks
 
-    def spy(cm, agg, var, enc, bf16):
+    def spy(cm, agg, var, enc, bf16, **kw):
         seen.append(bool(bf16))
-        return real(cm, agg, var, enc, bf16)
+        return real(cm, agg, var, enc, bf16, **kw)
     train_ops.canonical_trunks = spy
     try:
         outs = []
