@@ -161,8 +161,9 @@ TRAIN_BYTES_PER_ROW = {
     'aggregation weights (idx 160 -> atts 160, var 4)': 324,
     'hash encoding forward (enc_in 16 -> 128)': 144,
     'aggregation forward (idx 160, atts 160 -> 140)': 460,
-    'X0 assembly (agg 140, var 4, enc 128 -> 192)': 464,
-    'ten linear layers forward (inputs read, activations written once)': 8976,
+    # round 6: one kernel (csrc/trunks.hip) -- the 68 fp32 inputs read, X0 192 + 8 x 512 + GEO 192 + raw4 16 written, no
+    # activation read back (rounds 2-5: X0 assembly 464 + ten layer passes 8 976 = 9 440 B per row)
+    'trunks forward, fused (agg 140, var 4, enc 128 -> X0, A1..A4, GEO, B1..B4, raw4)': 4768,
     'compositing forward + backward (raw 20, mask 4, z 4; d_raw 20, d_mask 4)': 80,
     'linear layers backward: 10 weight-gradient passes (dZ + X) and 10 input-gradient passes (dZ + ReLU mask -> dX)': 24768,
     'aggregation backward (grad rows 140, idx 160, atts 160, run sums 140)': 600,
@@ -233,7 +234,7 @@ def train_leg(dev, steps, warmup):
             loss = step()
         torch.cuda.synchronize()
         timing[name] = (time.perf_counter() - t0) / steps
-    dt = timing['patches']
+    dt = timing['scattered']
     net.cfg.train_precision = 'auto'
     rows = TRAIN_RAYS * SPP
     nbytes = rows * sum(TRAIN_BYTES_PER_ROW.values()) + TRAIN_PARAM_BYTES
@@ -242,8 +243,15 @@ def train_leg(dev, steps, warmup):
     from occnerf_amd import train_graph
     pg = train_graph.get(net)
     traffic, traffic_src = train_pmc_traffic()
-    return {'ms_per_step': dt * 1e3, 'batch': '6 random 32 x 32-pixel patches of the 512 x 512 frame (the reference\'s patch sampling)',
-            'scattered_ms_per_step': timing['scattered'] * 1e3, 'rays_per_step': TRAIN_RAYS, 'samples_per_step': rows,
+    return {'ms_per_step': dt * 1e3,
+            'batch': '6 144 rays scattered over the 512 x 512 frame: the batch rounds 2-5 measured (round 5 reported it as '
+                     'scattered_ms_per_step), kept as the headline of this leg for continuity',
+            'patches_ms_per_step': timing['patches'] * 1e3,
+            'patches_batch': '6 patches of 32 x 32 pixels lying WHOLLY on bbox-hitting pixels (patch_ray_selection(full=True)): the '
+                             'shape of the reference\'s patch batch (default.yaml patch.N_patches 6, size 32) but not its sampling '
+                             'rule -- the reference accepts patches by mask coverage, which need not fill them; coherent patches '
+                             'collapse into more runs and are slightly faster',
+            'rays_per_step': TRAIN_RAYS, 'samples_per_step': rows,
             'rays_per_s': TRAIN_RAYS / dt, 'dtype': 'bf16 MLP trunks (fp32 accumulate, fp32 master weights); '
             'fp32 sampler, encoder, aggregation, compositor', 'final_loss': float(loss.detach()),
             'what': 'forward + backward + clip_grad_norm + Adam, every per-sample stage a HIP kernel '
@@ -659,6 +667,10 @@ def main():
             # of `value` -- the headline stays the exact fp32 kernel.  The kernel's own launches are timed with HIP events.
             net.cfg.mlp_precision = 'f16x3'
             net.invalidate_cache()
+            # (the out-of-domain flag: checked after every frame -- one wait per frame, the renderer's default -- for
+            # `checked_per_frame_ms_per_step`; checked behind the pipelined loop, Network.check_f16x3_domain(), for the leg's figure)
+            dts2, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
+            net.cfg.f16x3_domain_check = 'deferred'
             ev2, real_mlp2 = [], ops.canonical_mlp_bf16x3
 
             def timed_mlp2(*a, **k):
@@ -679,12 +691,18 @@ def main():
             net.cfg.dedup_repeated_samples = True
             dtb2, _ = timed_steps(renderer, frame_h, args.steps, args.warmup, rank, world, dev, 'bench', host_out)
             net.cfg.dedup_repeated_samples = False
+            net.check_f16x3_domain()                      # raises if any of the frames above left the mode's domain
+            net.cfg.f16x3_domain_check = True
             live2 = float(net.last_live_count) if getattr(net, 'last_live_count', None) is not None else None
             side['alt2'] = {'mlp_precision': 'f16x3 (two fp16 pieces per operand kept in the normal range: 22 significand bits, 3 MFMA '
                                              'products on v_mfma_f32_32x32x16_f16, fp32 accumulate): meets the fp32 kernel\'s own tolerances '
-                                             'and the 1e-4 pixel gate on all three checkpoints (tests/test_hip_parity.py *_f16x3); domain: '
+                                             'and the 1e-4 pixel gate on all three checkpoints (tests/test_y_alternatives.py *_f16x3); domain: '
                                              'hidden activations below 4 094',
                             'value': R * args.steps / dta2, 'unit': 'rays/s', 'ms_per_step': dta2 / args.steps * 1e3,
+                            'domain_check': "cfg.f16x3_domain_check='deferred': every frame's out-of-domain flag copied behind the frame "
+                                            'and verified after the loop (none set); checked_per_frame_ms_per_step = the default, one '
+                                            'wait per frame with an fp32 re-render on violation',
+                            'checked_per_frame_ms_per_step': dts2 / args.steps * 1e3,
                             'canonical_mlp_launch_ms': mlp2_ms,
                             'canonical_mlp_algorithmic_tflops': None if not (mlp2_ms and live2) else
                             FLOP_PER_SAMPLE_CNL * live2 / (mlp2_ms * 1e-3) / 1e12,

@@ -30,7 +30,7 @@ like a learnt surface -- so that softplus(sigma) x step covers per-sample alphas
 above 0.5 and rays end anywhere between transparent and opaque,
 centimetre-scale non-rigid offsets, milliradian pose corrections, non-uniform visibility
 counts and point offsets as in the amplified recipe.  What the parity tests hold on it, exactly
-(tests/test_hip_parity.py, profiles/r05_parity_truth.md): against the reference's float32 output, rgb and
+(tests/test_a_rows.py, profiles/r05_parity_truth.md): against the reference's float32 output, rgb and
 alpha within 1e-4 on every ray that holds no sample on a neighbour-set / inside-vote discontinuity
 (4 116 such rays: 2 x 2 048 "truth" fixtures + 224 tie-free ones), depth (scene units, up to 6.3) within
 1e-4 on 99.7 % of them, 2.4e-4 at worst -- on a field where the reference's own float32 run is up to

@@ -98,7 +98,9 @@ _DEFAULTS = {
     # significand bits per operand -- fp32-grade (csrc/split.h; domain: hidden activations below 4 094); 'bf16x3':
     # split-bf16 MFMA, 16 bits per operand (meets the pixel gate on the random-init checkpoint only)
     'mlp_precision': 'fp32',
-    'f16x3_domain_check': True,      # mlp_precision='f16x3': read the kernels' out-of-domain flag after the frame, re-render in fp32 when set
+    # mlp_precision='f16x3': True / 'sync' reads the kernels' out-of-domain flag after the frame and re-renders in fp32 when set;
+    # 'deferred' checks it when a later frame starts / in Network.check_f16x3_domain() and raises; False: no check
+    'f16x3_domain_check': True,
     'train_fused_trunks': True,      # bf16 training step: the trunks' forward as one kernel (csrc/trunks.hip); False: ten layer passes
     'skip_empty_samples': True,      # drop samples whose motion-weight sum is exactly 0 (identical pixels)
     'device_rays': True,             # run.py: generate the frame's ray batch on the GPU (occnerf_amd/rays.py)

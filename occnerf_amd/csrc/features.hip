@@ -234,7 +234,11 @@ __device__ __forceinline__ void level_taps_select(const float (&x)[4], const flo
         const uint32_t ia = a01[idx & 3] + a23[idx >> 2];
         const uint32_t ix = (x01[idx & 3] ^ x23[idx >> 2]) & lr.mask;
         const uint32_t index = lr.dense ? ia : ix;
+#ifdef OCC_FEAT_EXP_RESIDENT_HASH      // (tools/features_fetch_bound.py: every corner gather made an L1 hit -- the bound of any fetch-side change)
+        tp.v[idx] = ld32(grid, (lr.entry0 + (index & 63u)) * 8u);
+#else
         tp.v[idx] = ld32(grid, (lr.entry0 + index) * 8u);
+#endif
     }
 }
 
@@ -737,7 +741,11 @@ __global__ __launch_bounds__(LDS_TAIL ? 768 : 256, 3) void sample_features8_kern
                 for (int h = 0; h < 2; h++) {
 #pragma unroll
                     for (int k = 0; k < 5; k++)
+#ifdef OCC_FEAT_EXP_RESIDENT_ROWS      // (tools/features_fetch_bound.py: the 40 table rows of every sample taken from 16 rows)
+                        t[h * 5 + k] = ld32(table, (uint32_t)(__shfl(cur.id5[k], 2 * c + h, 8) & 15) * (uint32_t)(kTableStride * 4) + piece);
+#else
                         t[h * 5 + k] = ld32(table, (uint32_t)__shfl(cur.id5[k], 2 * c + h, 8) * (uint32_t)(kTableStride * 4) + piece);
+#endif
                 }
             };
             float4 b0[10], b1[10], b2[10];

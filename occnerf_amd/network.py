@@ -118,6 +118,23 @@ class Network(nn.Module):
     def point_cloud(self):
         return self.point_base + self.point_dist
 
+    def check_f16x3_domain(self, wait=True):
+        """cfg.f16x3_domain_check = 'deferred': look at the out-of-domain flags of the frames rendered so far (wait=False: only
+        those whose copy has completed).  Raises RuntimeError naming the first frame whose activations left the f16x3 domain --
+        its pixels were computed with saturated activations and must be rendered again with mlp_precision = 'fp32'."""
+        pending = self.__dict__.get('_f16x3_pending')
+        while pending:
+            done, host, frame_no = pending[0]
+            if not wait and not done.query():
+                return
+            done.synchronize()
+            pending.pop(0)
+            if int(host[0]) != 0:
+                pending.clear()
+                raise RuntimeError(f"occnerf_amd: frame {frame_no} of this Network left the domain of cfg.mlp_precision='f16x3' (a hidden "
+                                   'activation reached 4 094): its pixels are not fp32-grade -- render it with mlp_precision=\'fp32\' '
+                                   "(cfg.f16x3_domain_check=True does that by itself, at the price of one wait per frame)")
+
     def invalidate_cache(self):
         """Drop the device-side constants and packed weights (load_state_dict and .to() do; in-place weight updates
         are noticed by themselves through the parameters' version counters)."""
@@ -503,6 +520,7 @@ class Network(nn.Module):
 
         if fused:
             # ---- render: 3 launches of per-frame preamble (csrc/preamble.hip), then the sample pipeline ----
+            self.check_f16x3_domain(wait=False)      # (cfg.f16x3_domain_check = 'deferred': earlier frames whose flag has arrived)
             with torch.no_grad():
                 wc = self._weight_constants()
                 pack = self._point_pack(wc)
@@ -547,11 +565,23 @@ class Network(nn.Module):
                             self._render_rays(rays8[i:i + n], Rs, Ts, vol, bbox_min, bbox_scale, bgcolor, cond, hann.tolist(),
                                               wc['table'], out=tuple(t[i:i + n] for t in out), pack=pack, boxes=boxes, center=center)
                 passes()
-                # f16x3 is exact-grade only inside its domain (hidden activations below 4 094: csrc/split.h); its kernels
-                # report leaving it and the frame is then rendered again with the fp32 kernels -- never silently wrong pixels.
-                # (The read waits for the frame; cfg.f16x3_domain_check=False skips it and the guarantee.)
-                flag = self._packed_weights().get('domain_flag') if R > 0 else None
-                if flag is not None and cfg.get('f16x3_domain_check', True) and int(flag.item()) != 0:
+                # f16x3 is exact-grade only inside its domain (hidden activations below 4 094: csrc/split.h); its kernels report
+                # leaving it -- never silently wrong pixels.  cfg.f16x3_domain_check: True / 'sync' (default) reads the flag after
+                # the frame (the read waits for the frame) and renders the frame AGAIN with the fp32 kernels when it is set;
+                # 'deferred' copies the flag to pinned memory behind the frame and looks at it when a later frame starts (or in
+                # check_f16x3_domain()): no wait in a pipelined loop, and a violation RAISES there, naming the frame, because
+                # that frame's pixels have already been handed out; False skips the check and the guarantee.
+                mode = cfg.get('f16x3_domain_check', True)
+                flag = self._packed_weights().get('domain_flag') if (R > 0 and mode) else None
+                self._frames_rendered = getattr(self, '_frames_rendered', 0) + 1
+                if flag is not None and mode == 'deferred':
+                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    host.copy_(flag, non_blocking=True)
+                    flag.zero_()
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream(dev))
+                    self.__dict__.setdefault('_f16x3_pending', []).append((done, host, self._frames_rendered))
+                elif flag is not None and int(flag.item()) != 0:
                     flag.zero_()
                     self.f16x3_fallback_frames = getattr(self, 'f16x3_fallback_frames', 0) + 1
                     if self.f16x3_fallback_frames == 1:

@@ -238,7 +238,7 @@ def test_make_golden_reproduces_committed_fixtures(tmp_path):
 def test_oracle_against_the_float64_truth(oracle):
     """The trained-like truth fixture (2 048 rays, reference in float32 and in float64): the CPU oracle chain on every 8th
     ray is as close to the float64 truth as the reference's own float32 run is (three-way table printed); the full set runs
-    on the GPU box against HIP (tests/test_hip_parity.py::test_trained_truth_three_way)."""
+    on the GPU box against HIP (tests/test_a_rows.py::test_trained_truth_three_way)."""
     from oracle.chain import golden_frame, model_context, stagewise_oracle_render
     g = util.load_golden('freeview_trained_truth_s32')
     assert g['truth.depth'].dtype == np.float64 and g['out.depth'].dtype == np.float32 and g['in.rays'].shape[1] == 2048

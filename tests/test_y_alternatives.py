@@ -244,3 +244,24 @@ def test_f16x3_reports_leaving_its_domain():
     for k in ('rgb', 'alpha', 'depth'):
         assert torch.equal(got[k], want[k]) and torch.equal(got2[k], want[k]), k
     assert net.cfg.mlp_precision == 'f16x3'
+
+
+def test_f16x3_deferred_domain_check_raises_for_the_right_frame():
+    """cfg.f16x3_domain_check = 'deferred': no wait per frame; a frame that left the domain is named when its flag has arrived
+    (explicit check_f16x3_domain(), or the start of a later frame), frames inside the domain pass silently."""
+    g = util.load_golden('freeview_amp_s32')
+    nr = bool(int(g['meta.non_rigid']))
+    data = frame_to_device(g, DEV)
+    net, _ = build_network(int(g['meta.seed']), util.level(g), S=int(g['meta.S']), non_rigid=nr, mlp_precision='f16x3')
+    net.cfg.f16x3_domain_check = 'deferred'
+    with torch.no_grad():
+        for _ in range(3):
+            net(**data, iter_val=1e7)
+    net.check_f16x3_domain()                                   # three frames inside the domain
+    with torch.no_grad():
+        net.cnl_mlp.module.pts_linears[0].weight.mul_(3e4)
+        net.cnl_mlp.module.pts_linears[0].bias.mul_(3e4)
+        net(**data, iter_val=1e7)                              # frame 4: outside
+    with pytest.raises(RuntimeError, match='frame 4'):
+        net.check_f16x3_domain()
+    net.check_f16x3_domain()                                   # reported once, then clean

@@ -6,7 +6,7 @@ tag=$1
 export TMPDIR=/tmp
 o=gpurun_out/$tag
 mkdir -p $o
-python3 bench.py > $o/bench_line.json 2> $o/bench.err
+timeout -k 5 900 python3 bench.py > $o/bench_line.json 2> $o/bench.err
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_bench -o b -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt > $o/prof_bench_line.json 2> $o/prof_bench.err
 cat > /tmp/dd_frame.py <<'PY'
 import sys, torch
@@ -31,9 +31,8 @@ for m in 0 1 2; do
   timeout -k 5 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/fc$m -o p -- /tmp/fc $m > $o/fc$m.log 2>&1
 done
 hipcc --offload-arch=gfx950 -O3 -o /tmp/mir tools/mfma_issue_rate.hip 2>/dev/null && /tmp/mir > $o/mfma_issue_rate.txt 2>&1
-# the split-operand (f16x3 / bf16x3) MLP kernels: MFMA counters of the alt2 leg, phase stamps, zero-operand clock test
+# the split-operand (f16x3 / bf16x3) MLP kernels: MFMA counters of the alt2 leg
 timeout -k 5 400 bash tools/pmc_mfma.sh $o/pmc_mfma_alt2.json "--only alt2" > $o/pmc_mfma_alt2.log 2>&1
-timeout -k 5 300 python3 tools/split_kernel_phases.py > $o/split_kernel_phases.txt 2>&1
 # the training step: kernel summary, torch-level profile, HBM counters of every kernel
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_train -o t -- python3 tools/train_step_trace.py 10 > $o/train_trace.log 2>&1
 timeout -k 5 300 python3 tools/train_step_profile.py > $o/train_step_profile_bf16.txt 2>&1
