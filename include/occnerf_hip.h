@@ -373,8 +373,9 @@ int occnerf_sample_features_centered(const float *xyz, int64_t N, const int32_t 
  * atts[N,K] (detached in the reference).  Backward: partial[W,P,F] with W = occnerf_agg_backward_slices(N);
  * every element is written, grad_feats = partial.sum(0).  Workgroups own (sample slice, point tile) pairs
  * and accumulate in LDS -- no global atomics; a first pass sums the gradient rows of runs of consecutive samples with
- * identical neighbour lists (K <= 64; atts must be a function of the ids, as simple_agg's are) into `scratch`
- * (occnerf_agg_backward_scratch_bytes(N, F) bytes) so that a run is scattered once.  Replaces torch's feats[knn]
+ * bitwise identical neighbour lists AND weights (K <= 64; arbitrary atts are exact: round 6 compares them too) into `scratch`
+ * (occnerf_agg_backward_scratch_bytes(N, F) bytes) so that a run is scattered once.  Limits, refused by name: F <= 64, K <= 64 in
+ * the backward, and at most 32 point tiles (P <= 32 x min(1024, 18432 / F) rows: 16 832 at F = 35).  Replaces torch's feats[knn]
  * materialisation and its index_put backward. */
 int occnerf_agg_forward(const float *feats, int32_t F, const int32_t *knn, const float *atts, int64_t N, int32_t K,
                         float *agg, void *stream);

@@ -10,9 +10,9 @@
 
 namespace occ {
 
-// (round 5) A wave takes kAggFwdRun consecutive samples: a sample whose 40 ids equal its predecessor's -- a run of collapsed
-// samples, see the backward below -- has the same weights (a function of the ids) and therefore the same sum: it is copied,
-// not gathered again.
+// (round 5) A wave takes kAggFwdRun consecutive samples: a sample whose 40 ids AND 40 weights are bitwise its predecessor's -- a
+// run of collapsed samples, see the backward below -- has the same sum: it is copied, not gathered again.  (Round 6: the weights
+// are compared too.  On the training path they are a function of the ids, but nothing in this entry point's signature says so.)
 constexpr int kAggFwdRun = 8;
 
 __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restrict__ feats, int F,
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restric
     if (n0 >= N) return;
     const int64_t n1 = n0 + kAggFwdRun < N ? n0 + kAggFwdRun : N;
     int prev_id = -2;
+    uint32_t prev_w = 0u;
     float acc = 0.0f;
     for (int64_t n = n0; n < n1; n++) {
         const int32_t *id = knn + n * K;
@@ -31,8 +32,10 @@ __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restric
         bool same = K <= 64;
         if (same) {
             const int my = lane < K ? id[lane] : -1;
-            same = __builtin_amdgcn_ballot_w64(my != prev_id) == 0ull;
+            const uint32_t myw = lane < K ? __float_as_uint(w[lane]) : 0u;
+            same = __builtin_amdgcn_ballot_w64(my != prev_id || myw != prev_w) == 0ull;
             prev_id = my;
+            prev_w = myw;
         }
         if (!same) {
             acc = 0.0f;
@@ -64,8 +67,9 @@ __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restric
 //   1. agg_runs_kernel, once over the samples: wherever a sample's motion-weight sum is far below the warp's 1e-4 clamp
 //      its canonical position collapses onto one point (network.py:388; two thirds of a frame's live samples), so
 //      consecutive samples of a ray carry the SAME 40 neighbour ids in the same order -- hence the same softmax weights,
-//      a function of the ids alone (occnerf_mlp.py:110-125).  A wave walks 64 contiguous samples, sums the gradient rows
-//      of each run of identical id lists (fp64 in registers) into the row of the run's FIRST sample, and writes per sample
+//      a function of the ids alone (occnerf_mlp.py:110-125; the kernel compares the weights' bits as well, so arbitrary
+//      atts are handled exactly).  A wave walks 64 contiguous samples, sums the gradient rows
+//      of each run of identical (ids, weights) lists (fp64 in registers) into the row of the run's FIRST sample, and writes per sample
 //      a bit mask of the point tiles its ids touch -- zero for every sample but a run's first, and for runs whose summed
 //      row is exactly zero (dead samples: alpha is multiplied by a zero mask).
 //   2. agg_backward_tiled_kernel: a (tile, slice) job reads 4 bytes per sample -- the masks, coalesced -- and fetches
@@ -74,7 +78,8 @@ constexpr int kAggTileValues = 18432;            // doubles: 144 KiB of LDS
 constexpr int kAggRun = 64;                      // samples a wave walks for runs (half a ray at 128 samples / ray)
 
 __global__ __launch_bounds__(256) void agg_runs_kernel(const float *__restrict__ grad_agg, int F,
-                                                       const int32_t *__restrict__ knn, int64_t N, int K, int tile_points,
+                                                       const int32_t *__restrict__ knn, const float *__restrict__ atts,
+                                                       int64_t N, int K, int tile_points,
                                                        int tiles, float *__restrict__ gsum /*[N][F]*/,
                                                        uint32_t *__restrict__ mask /*[N]*/) {
     const int lane = threadIdx.x & 63;
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(256) void agg_runs_kernel(const float *__restrict__
     const int64_t c1 = c0 + kAggRun < N ? c0 + kAggRun : N;
     constexpr int U = 8;
     int cur_id = -2;                 // the open run's id list (lane j: neighbour j) ...
+    uint32_t cur_w = 0u;             // ... and weight bits ...
     double acc = 0.0;                // ... the sum of its gradient rows (lane c: column c) ...
     int head = -1;                   // ... and its first sample (offset in the chunk)
     uint32_t my_mask = 0;            // lane i: mask of sample c0 + i
@@ -99,18 +105,21 @@ __global__ __launch_bounds__(256) void agg_runs_kernel(const float *__restrict__
     for (int64_t nb = c0; nb < c1; nb += U) {
         float g[U];
         int my_id[U];
+        uint32_t my_w[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int64_t n = nb + u < c1 ? nb + u : c1 - 1;
             g[u] = lane < F ? grad_agg[n * F + lane] : 0.0f;
             my_id[u] = lane < K ? knn[n * K + lane] : -1;
+            my_w[u] = lane < K ? __float_as_uint(atts[n * K + lane]) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (nb + u >= c1) break;
-            if (head < 0 || __builtin_amdgcn_ballot_w64(my_id[u] != cur_id) != 0ull) {
+            if (head < 0 || __builtin_amdgcn_ballot_w64(my_id[u] != cur_id || my_w[u] != cur_w) != 0ull) {
                 if (head >= 0) flush();
                 cur_id = my_id[u];
+                cur_w = my_w[u];
                 acc = 0.0;
                 head = (int)(nb + u - c0);
             }
@@ -226,12 +235,13 @@ OCC_API int occnerf_agg_backward(const float *grad_agg, int32_t F, const int32_t
     const int W = occnerf_agg_backward_slices(N);
     const int tile_points = agg_tile_points(F);
     const int tiles = (P + tile_points - 1) / tile_points;
-    OCC_REQUIRE(tiles <= 32, "agg_backward: %d point tiles (P=%d): at most 32", tiles, P);
+    OCC_REQUIRE(tiles <= 32, "agg_backward: %d point tiles of %d rows for P=%d, F=%d: at most 32 (the per-sample tile mask is 32 bits "
+                "wide: P <= %d at this F)", tiles, tile_points, P, F, 32 * tile_points);
     float *gsum = reinterpret_cast<float *>(scratch);
     uint32_t *mask = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(scratch) + ((N * F * 4 + 255) & ~(int64_t)255));
     const int64_t chunks = (N + kAggRun - 1) / kAggRun;
     OCC_REQUIRE((chunks + 3) / 4 < (1ll << 31), "agg_backward: N too large");
-    hipLaunchKernelGGL(agg_runs_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, as_stream(stream), grad_agg, F, knn, N, K,
+    hipLaunchKernelGGL(agg_runs_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, as_stream(stream), grad_agg, F, knn, atts, N, K,
                        tile_points, tiles, gsum, mask);
     const int64_t per_slice = (((N + W - 1) / W) + kAggRun - 1) / kAggRun * kAggRun;      // whole chunks: runs never straddle a slice
     hipLaunchKernelGGL(agg_backward_tiled_kernel, dim3(W, tiles), dim3(1024), 0, as_stream(stream), gsum, F, knn, atts, mask,

@@ -301,7 +301,7 @@ __device__ __forceinline__ void load_step(bf16x8 (&ah)[OB], bf16x8 (&al)[OB], co
     }
 
 // relu(acc) -> the 16 split B operands of the next layer (2 per 32-feature block)
-template <typename P>
+template <typename P, bool WATCH = true>
 __device__ __forceinline__ void relu_split(SplitT<P> (&b)[2 * kOB], const f32x16 (&acc)[kOB], float &amax) {
 #pragma unroll
     for (int ob = 0; ob < kOB; ob++) {
@@ -310,16 +310,15 @@ __device__ __forceinline__ void relu_split(SplitT<P> (&b)[2 * kOB], const f32x16
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = P::relu(acc[ob][sub * 8 + i]);
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) P::watch(amax, acc[ob][sub * 8 + i], acc[ob][sub * 8 + i + 1]);
             b[ob * 2 + sub] = split8t<P>(v);
+            if constexpr (WATCH) P::watch_hi(amax, b[ob * 2 + sub].hi);
         }
     }
 }
 template <typename P>
 __device__ __forceinline__ void relu_split(SplitT<P> (&b)[2 * kOB], const f32x16 (&acc)[kOB]) {
     float unused = 0.0f;
-    relu_split<P>(b, acc, unused);
+    relu_split<P, false>(b, acc, unused);
 }
 
 __device__ __forceinline__ float dot_row_relu(const f32x16 (&acc)[kOB], const float *__restrict__ Wrow, int h) {
@@ -468,14 +467,14 @@ __device__ __forceinline__ void lds_bias(f32x16 (&acc)[OB], const float *aux, in
     }
 }
 
-template <typename P>
+template <typename P, bool WATCH /* P::kBounded policies: track the clamped values and report leaving the domain (split.h) */>
 __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     const float *__restrict__ mlp_in, const int32_t *__restrict__ in_rows /*nullable: input row of entry n*/, int64_t N_max,
     const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/, const float *__restrict__ pk,
     const typename P::V8 *__restrict__ pkh, float *__restrict__ raw, uint32_t *__restrict__ domain_flag /*nullable*/) {
     typedef typename P::V8 V8;
     typedef SplitT<P> Split;
-    float amax = 0.0f;      // largest scaled value this lane sent through a clamp (P::kBounded policies)
+    float amax = 0.0f;      // P::kBounded policies: running packed-half maximum of the clamped values' hi pieces (split.h)
     constexpr float kSx = P::kSx, kInvSx = 1.0f / P::kSx;
     const int64_t N = n_dev ? (int64_t)*n_dev : N_max;
     if ((int64_t)blockIdx.x * 128 >= N) return;      // launches are sized for the worst case; uniform per workgroup
@@ -513,9 +512,11 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = (s * 8 + i) < 34 ? P::sym(src[s * 8 + i] * kSx) : 0.0f;
+            if constexpr (WATCH) {
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if ((s * 8 + i) < 34) P::watch_abs(amax, src[s * 8 + i] * kSx);
+                for (int i = 0; i < 8; i++)
+                    if ((s * 8 + i) < 34) P::watch_abs(amax, src[s * 8 + i] * kSx);
+            }
             bx[s] = split8t<P>(v);
         }
     }
@@ -589,13 +590,13 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     lds_bias<kOB>(acc, aux + Aux::kGeoL0B, h);
 #define BOPS_X(s) bx[s]
     OCC_LAYER_LDS8(kS_L0Geo, acc, BOPS_X)
-    relu_split<P>(bact, acc, amax);
+    relu_split<P, WATCH>(bact, acc, amax);
 #define BOPS_ACT(s) bact[s]
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
         lds_bias<kOB>(acc, aux + Aux::kGeoHB + l * 256, h);
         OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
-        if (l < 2) relu_split<P>(bact, acc, amax);
+        if (l < 2) relu_split<P, WATCH>(bact, acc, amax);
     }
     float sigma;
     {
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         }
         sigma = (sacc + __shfl_xor(sacc, 32)) * kInvSx + aux[Aux::kSigma + 256];
     }
-    relu_split<P>(bact, acc, amax);
+    relu_split<P, WATCH>(bact, acc, amax);
     // geometry head: 2 output blocks; a chunk carries 4 k-steps [step][hi|lo][ob][lane]
     f32x16 geo[2];
     lds_bias<2>(geo, aux + Aux::kGeoHeadB, h);
@@ -645,8 +646,10 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = P::sym(geo[b][sub * 8 + i]);
+            if constexpr (WATCH) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) P::watch_abs(amax, geo[b][sub * 8 + i]);
+                for (int i = 0; i < 8; i++) P::watch_abs(amax, geo[b][sub * 8 + i]);
+            }
             bgeo[b * 2 + sub] = split8t<P>(v);
         }
     }
@@ -655,12 +658,12 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
     lds_bias<kOB>(acc, aux + Aux::kRgbL0B, h);
 #define BOPS_RGB0(s) ((s) < 4 ? bgeo[(s) & 3] : bx[((s) - 4) < 0 ? 0 : ((s) - 4)])
     OCC_LAYER_LDS8(kS_L0Rgb, acc, BOPS_RGB0)
-    relu_split<P>(bact, acc, amax);
+    relu_split<P, WATCH>(bact, acc, amax);
 #pragma unroll 1
     for (int l = 0; l < 3; l++) {
         lds_bias<kOB>(acc, aux + Aux::kRgbHB + l * 256, h);
         OCC_LAYER_LDS8(kS_Hidden, acc, BOPS_ACT)
-        if (l < 2) relu_split<P>(bact, acc, amax);
+        if (l < 2) relu_split<P, WATCH>(bact, acc, amax);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the 3 tail chunks: nobody reads them
     float rgb[3];
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(256, 1) void canonical_mlp_split_lds_kernel(
         o[2] = rgb[2];
         o[3] = sigma;
     }
-    split_report<P>(amax, domain_flag);
+    if constexpr (WATCH) split_report<P>(amax, domain_flag);
 #undef BOPS_X
 #undef BOPS_ACT
 #undef BOPS_RGB0
@@ -767,7 +770,7 @@ static int mlp_bf16x3_launch(const float *mlp_in, const int32_t *in_rows, int64_
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_bf16x3: N too large");
     const bf16x8 *pkh = reinterpret_cast<const bf16x8 *>(packed_bf16);
     if (variant == 0)
-        hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<Bf16x3>), dim3((unsigned)blocks), dim3(256), 0,
+        hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<Bf16x3, false>), dim3((unsigned)blocks), dim3(256), 0,
                            as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw, (uint32_t *)nullptr);
     else
         hipLaunchKernelGGL(canonical_mlp_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0,
@@ -796,8 +799,13 @@ OCC_API int occnerf_canonical_mlp_f16x3(const float *mlp_in, const int32_t *in_r
     OCC_REQUIRE(blocks < (1ll << 31), "canonical_mlp_f16x3: N too large");
     const f16x8 *pkh = reinterpret_cast<const f16x8 *>(packed_f16);
     const dim3 grid((unsigned)blocks), wg(256);
-    hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev, packed, pkh, raw,
-                       domain_flag);
+    // (the watched form costs ~6 % of the launch: callers that pass no flag word get the round-5 kernel)
+    if (domain_flag)
+        hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3, true>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev,
+                           packed, pkh, raw, domain_flag);
+    else
+        hipLaunchKernelGGL((canonical_mlp_split_lds_kernel<F16x3, false>), grid, wg, 0, as_stream(stream), mlp_in, in_rows, N_max, n_dev,
+                           packed, pkh, raw, domain_flag);
     return check_launch("canonical_mlp_f16x3");
 }
 

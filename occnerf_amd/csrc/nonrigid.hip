@@ -287,7 +287,7 @@ __device__ __forceinline__ void nr_glds16(const void *gbase, unsigned lane_off, 
                  : "memory");
 }
 
-template <typename P>
+template <typename P, bool WATCH /* track the ReLU outputs and report leaving the policy's domain (split.h) */>
 __global__ __launch_bounds__(256, 2) void nonrigid_split_kernel(const float *xyz_in /* may alias xyz_out (in-place): no __restrict__ */, int64_t N_max,
                                                                  const int32_t *__restrict__ rows /*nullable: sample of entry n*/,
                                                                  const int32_t *__restrict__ n_dev /*nullable: device-side entry count*/,
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void nonrigid_split_kernel(const float *xyz
                                                                  float *xyz_out, uint32_t *__restrict__ domain_flag /*nullable*/) {
     typedef typename P::V8 V8;
     typedef NrSplitT<P> NrSplit;
-    float amax = 0.0f;      // largest scaled value this lane sent through the ReLU clamp (split.h: P::kBounded policies)
+    float amax = 0.0f;      // P::kBounded policies: running packed-half maximum of the ReLU outputs' hi pieces (split.h)
     constexpr float kSx = P::kSx, kInvSx = 1.0f / P::kSx;
     __shared__ __attribute__((aligned(16))) V8 smem[kNrRing * kNrChunkUnits + NrAux::kTotal / 4];
     V8 *ring = smem;
@@ -398,8 +398,8 @@ __global__ __launch_bounds__(256, 2) void nonrigid_split_kernel(const float *xyz
         _Pragma("unroll") for (int sub = 0; sub < 2; sub++) {                                      \
             float v[8];                                                                            \
             _Pragma("unroll") for (int i = 0; i < 8; i++) v[i] = P::relu(acc[ob][sub * 8 + i]);    \
-            _Pragma("unroll") for (int i = 0; i < 8; i += 2) P::watch(amax, acc[ob][sub * 8 + i], acc[ob][sub * 8 + i + 1]); \
             bact[ob * 2 + sub] = nr_split8<P>(v);                                                  \
+            if constexpr (WATCH) P::watch_hi(amax, bact[ob * 2 + sub].hi);                         \
         }                                                                                          \
     }
 
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void nonrigid_split_kernel(const float *xyz
 #pragma unroll
         for (int c = 0; c < 3; c++) xyz_out[nsrc * 3 + c] = __fadd_rn(p[c], off[c]);
     }
-    split_report<P>(amax, domain_flag);
+    if constexpr (WATCH) split_report<P>(amax, domain_flag);
 #undef NR_STEP
 #undef NR_BIAS
 #undef NR_RELU_SPLIT
@@ -520,8 +520,12 @@ static int nr_split_launch(const float *xyz_in, int64_t N_max, const int32_t *ro
     for (int i = 0; i < 6; i++) prm.hann[i] = h_hann[i];
     const int64_t blocks = (N_max + 127) / 128;
     OCC_REQUIRE(blocks < (1ll << 31), "%s: N too large", what);
-    hipLaunchKernelGGL(nonrigid_split_kernel<P>, dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N_max, rows, n_dev, packed,
-                       reinterpret_cast<const typename P::V8 *>(packed_split), prm, xyz_out, domain_flag);
+    if (P::kBounded && domain_flag)
+        hipLaunchKernelGGL((nonrigid_split_kernel<P, true>), dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N_max, rows, n_dev, packed,
+                           reinterpret_cast<const typename P::V8 *>(packed_split), prm, xyz_out, domain_flag);
+    else
+        hipLaunchKernelGGL((nonrigid_split_kernel<P, false>), dim3((unsigned)blocks), dim3(256), 0, st, xyz_in, N_max, rows, n_dev, packed,
+                           reinterpret_cast<const typename P::V8 *>(packed_split), prm, xyz_out, domain_flag);
     return check_launch(what);
 }
 

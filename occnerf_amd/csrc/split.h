@@ -45,7 +45,7 @@ struct Bf16x3 {
     static __device__ __forceinline__ float relu(float a) { return fmaxf(a, 0.0f); }
     static __device__ __forceinline__ float sym(float a) { return a; }
     static constexpr bool kBounded = false;                 // no saturation: nothing to report
-    static __device__ __forceinline__ void watch(float &, float, float) {}
+    static __device__ __forceinline__ void watch_hi(float &, const V8 &) {}
     static __device__ __forceinline__ void watch_abs(float &, float) {}
 };
 struct F16x3 {
@@ -69,20 +69,37 @@ struct F16x3 {
     static __device__ __forceinline__ float relu(float a) { return __builtin_amdgcn_fmed3f(a, 0.0f, 65504.0f); }
     static __device__ __forceinline__ float sym(float a) { return __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f); }
     // Round 6: the clamps above are the edge of this mode's DOMAIN (scaled hidden activations below 65 504, i.e. activations
-    // below 4 094) and leaving it must not be silent: every value that goes through relu / sym also goes through a running
-    // per-lane maximum (one v_max3_f32 per two values); a wave whose maximum reached the bound sets the caller's flag word
-    // (split_report).  The host re-renders the frame with the fp32 kernels (Network.forward) -- see DESIGN.md section 3.
+    // below 4 094) and leaving it must not be silent.  A clamped value's hi piece IS 65 504, the largest fp16 number, so the ReLU
+    // outputs are watched on their hi pieces as they are produced: a running packed-half maximum, four v_pk_max_f16 per eight
+    // values, ONE register (carried as the bits of a float) -- watching the fp32 accumulators instead cost the non-rigid kernel
+    // its two-workgroups-per-CU register budget (176 spills).  Signed inputs (sym) are few and watched in fp32.  A wave whose
+    // maximum reached the bound sets the caller's flag word (split_report); the host re-renders the frame with the fp32 kernels
+    // (Network.forward) -- see DESIGN.md section 3.
     static constexpr bool kBounded = true;
     static constexpr float kBound = 65504.0f;
-    static __device__ __forceinline__ void watch(float &m, float a, float b) { m = fmaxf(fmaxf(m, a), b); }
-    static __device__ __forceinline__ void watch_abs(float &m, float a) { m = fmaxf(m, fabsf(a)); }
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    struct Quad { f16x2 q[4]; };
+    static __device__ __forceinline__ void watch_hi(float &m, const V8 &hi) {
+        f16x2 mm = __builtin_bit_cast(f16x2, m);
+        const Quad h = __builtin_bit_cast(Quad, hi);
+#pragma unroll
+        for (int i = 0; i < 4; i++) mm = __builtin_elementwise_max(mm, h.q[i]);
+        m = __builtin_bit_cast(float, mm);
+    }
+    static __device__ __forceinline__ void watch_abs(float &m, float a) {      // (|a| >= bound -> both halves of the packed maximum)
+        if (fabsf(a) >= kBound) m = __builtin_bit_cast(float, f16x2{(_Float16)65504.0f, (_Float16)65504.0f});
+    }
+    static __device__ __forceinline__ bool left_domain(float m) {
+        const f16x2 mm = __builtin_bit_cast(f16x2, m);
+        return (float)mm[0] >= kBound || (float)mm[1] >= kBound;
+    }
 };
 
 // one atomic per wave that left the domain (none on the documented domain); flag may be NULL
 template <typename P>
 __device__ __forceinline__ void split_report(float amax, uint32_t *flag) {
     if constexpr (P::kBounded) {
-        if (flag && __builtin_amdgcn_ballot_w64(amax >= P::kBound) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+        if (flag && __builtin_amdgcn_ballot_w64(P::left_domain(amax)) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
     }
 }
 

@@ -118,6 +118,23 @@ class Network(nn.Module):
     def point_cloud(self):
         return self.point_base + self.point_dist
 
+    def _f16x3_flag_word(self):
+        """A zero-initialised device word for f16x3 kernels launched outside the render path (the bf16 training step's offsets)."""
+        w = self.__dict__.get('_f16x3_word')
+        if w is None or w.device != self.point_base.device:
+            w = self.__dict__['_f16x3_word'] = torch.zeros(1, device=self.point_base.device, dtype=torch.int32)
+        return w
+
+    def _f16x3_enqueue_check(self, flag, what):
+        """Copy the flag word to pinned memory behind the work issued so far, clear it, and queue the copy for check_f16x3_domain."""
+        self._frames_rendered = getattr(self, '_frames_rendered', 0) + 1
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(flag, non_blocking=True)
+        flag.zero_()
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(flag.device))
+        self.__dict__.setdefault('_f16x3_pending', []).append((done, host, f'{what} {self._frames_rendered}'))
+
     def check_f16x3_domain(self, wait=True):
         """cfg.f16x3_domain_check = 'deferred': look at the out-of-domain flags of the frames rendered so far (wait=False: only
         those whose copy has completed).  Raises RuntimeError naming the first frame whose activations left the f16x3 domain --
@@ -131,9 +148,10 @@ class Network(nn.Module):
             pending.pop(0)
             if int(host[0]) != 0:
                 pending.clear()
-                raise RuntimeError(f"occnerf_amd: frame {frame_no} of this Network left the domain of cfg.mlp_precision='f16x3' (a hidden "
-                                   'activation reached 4 094): its pixels are not fp32-grade -- render it with mlp_precision=\'fp32\' '
-                                   "(cfg.f16x3_domain_check=True does that by itself, at the price of one wait per frame)")
+                raise RuntimeError(f"occnerf_amd: {frame_no} of this Network left the domain of the f16x3 kernels (a hidden activation "
+                                   'reached 4 094): its results are not fp32-grade -- use mlp_precision=\'fp32\' / '
+                                   "train_nonrigid_f16x3=False (a render with cfg.f16x3_domain_check=True falls back by itself, at the "
+                                   'price of one wait per frame)')
 
     def invalidate_cache(self):
         """Drop the device-side constants and packed weights (load_state_dict and .to() do; in-place weight updates
@@ -203,7 +221,7 @@ class Network(nn.Module):
         pack_c = {'bf16x3': ops.canonical_mlp_pack_bf16, 'f16x3': ops.canonical_mlp_pack_f16}.get(prec)
         pack_n = {'bf16x3': ops.nonrigid_pack_bf16, 'f16x3': ops.nonrigid_pack_f16}.get(prec)
         srcs = cw + cb + [m.weight for m in nr_lin] + [m.bias for m in nr_lin]
-        key = (prec,) + tuple((t.data_ptr(), t._version) for t in srcs)
+        key = (prec, str(self.cfg.get('f16x3_domain_check', True))) + tuple((t.data_ptr(), t._version) for t in srcs)
         if self._packed is not None and self._packed['key'] == key:
             return self._packed
         self._packed = {
@@ -215,7 +233,8 @@ class Network(nn.Module):
             'nr_bf16': pack_n([m.weight.detach() for m in nr_lin]) if pack_n else None,
             'nr_w0': nr_lin[0].weight.detach(), 'nr_b0': nr_lin[0].bias.detach(),
             # f16x3: the word its kernels set when a hidden activation reaches the mode's clamp (4 094; csrc/split.h)
-            'domain_flag': torch.zeros(1, device=cw[0].device, dtype=torch.int32) if prec == 'f16x3' else None,
+            'domain_flag': torch.zeros(1, device=cw[0].device, dtype=torch.int32)
+            if (prec == 'f16x3' and self.cfg.get('f16x3_domain_check', True)) else None,
         }
         return self._packed
 
@@ -573,14 +592,8 @@ class Network(nn.Module):
                 # that frame's pixels have already been handed out; False skips the check and the guarantee.
                 mode = cfg.get('f16x3_domain_check', True)
                 flag = self._packed_weights().get('domain_flag') if (R > 0 and mode) else None
-                self._frames_rendered = getattr(self, '_frames_rendered', 0) + 1
                 if flag is not None and mode == 'deferred':
-                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-                    host.copy_(flag, non_blocking=True)
-                    flag.zero_()
-                    done = torch.cuda.Event()
-                    done.record(torch.cuda.current_stream(dev))
-                    self.__dict__.setdefault('_f16x3_pending', []).append((done, host, self._frames_rendered))
+                    self._f16x3_enqueue_check(flag, 'frame')
                 elif flag is not None and int(flag.item()) != 0:
                     flag.zero_()
                     self.f16x3_fallback_frames = getattr(self, 'f16x3_fallback_frames', 0) + 1
@@ -600,6 +613,7 @@ class Network(nn.Module):
             # ---- differentiable path: per-frame modules in torch (gradients to the pose refiner and the volume
             # decoder), then HIP forward + HIP backward per stage (train_path.py) ----
             from . import train_path
+            self.check_f16x3_domain(wait=False)      # (the bf16 step's f16x3 offsets: flags of earlier steps that have arrived)
             with torch.set_grad_enabled(want_grad):
                 # the per-frame modules always run in fp32 (bone transforms in bf16 would move every sample); a caller's
                 # torch.autocast(bfloat16) selects the arithmetic of the MLP trunks only (train_path._use_bf16)

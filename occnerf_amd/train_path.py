@@ -296,7 +296,13 @@ def render_rays_autograd(net, rays8, Rs, Ts, vol, bbox_min, bbox_scale, bgcolor,
             if bf16 and cfg.get('train_nonrigid_f16x3', True):
                 # bf16 step: the offsets (no gradient reaches this MLP, occnerf_mlp.py:144-167) on the fp32-grade split-fp16
                 # kernels (csrc/split.h; <= 1e-6 m from the fp32 kernel, 2.6x faster)
-                xyz = ops.nonrigid_bf16x3(cnl, condv, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], net._nonrigid_f16_pack())
+                # (its out-of-domain flag is copied behind the step and looked at when a later step starts: a step whose
+                # activations reached the f16x3 clamp raises there -- Network.check_f16x3_domain)
+                flag = net._f16x3_flag_word() if cfg.get('f16x3_domain_check', True) else None
+                xyz = ops.nonrigid_bf16x3(cnl, condv, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'], net._nonrigid_f16_pack(),
+                                          domain_flag=flag)
+                if flag is not None:
+                    net._f16x3_enqueue_check(flag, 'training step')
             else:
                 xyz = ops.nonrigid(cnl, condv, hann, pk['nr_w0'], pk['nr_b0'], pk['nr'])
         if cfg.get('knn_center_cache', True) and cfg.get('knn_culling', True):

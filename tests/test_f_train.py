@@ -800,3 +800,19 @@ def test_aggregate_autograd(ops):
     assert (got2.double() - want2).abs().max().item() <= 2e-6          # (the forward copies a run's sum instead of gathering again)
     gg2, = torch.autograd.grad(got2, f32, gout2)
     assert (gg2.double() - gw2).abs().max().item() <= 2e-6 * gw2.abs().max().item()
+    # round 6: identical id lists with DIFFERENT weights are not a run -- the weights' bits are compared too, so
+    # arbitrary atts through this entry point are exact
+    ids3 = ids.clone()
+    ids3[100:400] = ids3[100]
+    w3 = torch.softmax(torch.randn(N2, K, device=DEV), dim=1)          # every sample its own weights
+    want3 = (w3.double()[..., None] * f64[ids3.long()]).sum(1)
+    gw3, = torch.autograd.grad(want3, f64, gout2.double())
+    f33 = feats.detach().clone().requires_grad_(True)
+    got3 = ops.aggregate(f33, ids3, w3)
+    assert (got3.double() - want3).abs().max().item() <= 2e-6
+    gg3, = torch.autograd.grad(got3, f33, gout2)
+    assert (gg3.double() - gw3).abs().max().item() <= 2e-6 * gw3.abs().max().item()
+    # ... and the limits are refused by name, not silently wrong
+    with pytest.raises(RuntimeError, match='point tiles'):
+        big = torch.randn(17000, Fd, device=DEV, requires_grad=True)
+        torch.autograd.grad(ops.aggregate(big, ids3, w3).sum(), big)
