@@ -282,6 +282,137 @@ struct ClusteredScales {
     int seed[4];
 };
 
+// ---------------------------------------------------------------------------------------
+// ONE query per lane (round 6): the form small launches use for their SPREAD tiles.  A tile whose 256 queries are spread over the
+// body -- 64 neighbouring rays whose samples warp to different bones -- makes its wave scan most of the four point sets for all
+// four queries of every lane: 8 x the average tile (per-tile stamps, profiles/r06_knn_split_tiles.md).  On a full frame such tiles
+// hide among 30 tiles per wave; on a rank's eighth of a frame (3.7 tiles per wave) or a training batch (ONE tile per wave) the
+// longest tile IS the kernel.  There a spread tile is handed out as FOUR jobs, sample slot a of its 64 rays each, to four waves,
+// which search with this scalar form: half the arithmetic per point, and the clusters in reach of 64 queries that share a depth
+// slab.  Same distance formula, same keys, same conservative sphere tests as the four-query form: identical indices.
+// ---------------------------------------------------------------------------------------
+struct OneQuery {
+    float x, y, z;
+    bool live;
+};
+
+#define OCC_PT1(P)                                                                          \
+    {                                                                                       \
+        const float dx = q.x - P.x, dy = q.y - P.y, dz = q.z - P.z;                         \
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));           \
+        consider_lex(best, thr, sb, d2, __float_as_int(P.w));                               \
+    }
+#define OCC_SCAN1(JB, JE)                                                                   \
+    {                                                                                       \
+        const int je_ = (JE);                                                               \
+        int j = (JB);                                                                       \
+        float4 n0 = points[j], n1 = points[j + 1], n2 = points[j + 2], n3 = points[j + 3];  \
+        for (; j < je_; j += 4) {                                                           \
+            const float4 p0 = n0, p1 = n1, p2 = n2, p3 = n3;                                \
+            const int jn = j + 4 < je_ ? j + 4 : j;                                         \
+            n0 = points[jn], n1 = points[jn + 1], n2 = points[jn + 2], n3 = points[jn + 3]; \
+            OCC_PT1(p0) OCC_PT1(p1) OCC_PT1(p2) OCC_PT1(p3)                                 \
+        }                                                                                   \
+    }
+#define OCC_EMIT1(L)                                                                        \
+    if (q.live) {                                                                           \
+        struct __attribute__((packed, aligned(4))) I4 { int v[4]; };                        \
+        struct __attribute__((packed, aligned(4))) I2 { int v[2]; };                        \
+        int32_t *out = knn_idxs + (qi * sc.nscale + (L)) * kK;                              \
+        int r_[kK];                                                                         \
+        _Pragma("unroll") for (int p = 0; p < kK; p++) r_[p] = key_row(best.k[p]) & 0xFFFF; \
+        *reinterpret_cast<I4 *>(out) = I4{{r_[0], r_[1], r_[2], r_[3]}};                    \
+        *reinterpret_cast<I4 *>(out + 4) = I4{{r_[4], r_[5], r_[6], r_[7]}};                \
+        *reinterpret_cast<I2 *>(out + 8) = I2{{r_[8], r_[9]}};                              \
+    }
+
+__device__ __forceinline__ void search_one_query(const OneQuery q, const int64_t qi, const int lane,
+                                                 const float4 *__restrict__ points, const float4 *__restrict__ centers,
+                                                 const int2 *__restrict__ ranges, const float *__restrict__ radius,
+                                                 const float4 *__restrict__ gcenters, const int2 *__restrict__ granges,
+                                                 const float *__restrict__ gradius, const ClusteredScales &sc,
+                                                 int32_t *__restrict__ knn_idxs) {
+    KBest64 best;
+    float thr = q.live ? INFINITY : -1.0f, sb = INFINITY;
+    kbest64_reset(best);
+    OCC_SCAN1(sc.coarse_begin, sc.coarse_end)
+    OCC_EMIT1(sc.nscale - 1)
+    // reference point of the "nearest cluster first" choice: the first live query of the wave
+    const unsigned long long lv = __builtin_amdgcn_ballot_w64(q.live);
+    const int first = lv ? __builtin_ctzll(lv) : 0;
+    const float rx = __shfl(q.x, first), ry = __shfl(q.y, first), rz = __shfl(q.z, first);
+    for (int l = sc.nscale - 2; l >= 0; l--) {
+        sb = sc.seed[l] ? key_dist(best.k[kK - 1]) : INFINITY;
+        thr = q.live ? filter_bound(sb) : -1.0f;
+        kbest64_reset(best);
+        const int2 *rg = ranges + (size_t)l * sc.ncl;
+        const float *rd = radius + (size_t)l * sc.ncl;
+        int k_first;
+        {
+            float bd = INFINITY;
+            int bk = 0;
+            for (int k = lane; k < sc.ncl; k += kWave) {
+                const float4 c = centers[k];
+                const float dx = rx - c.x, dy = ry - c.y, dz = rz - c.z;
+                const float d = dx * dx + dy * dy + dz * dz;
+                const bool has = rg[k].x < rg[k].y;
+                if (has && d < bd) {
+                    bd = d;
+                    bk = k;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float od = __shfl_xor(bd, o);
+                const int ok = __shfl_xor(bk, o);
+                if (od < bd || (od == bd && ok < bk)) {
+                    bd = od;
+                    bk = ok;
+                }
+            }
+            k_first = __builtin_amdgcn_readfirstlane(bk);
+        }
+        {
+            const int2 range = rg[k_first];
+            OCC_SCAN1(range.x, range.y)
+        }
+        auto in_reach = [&](const float4 c, const float r) -> bool {
+            const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const float lim = (sb + r) * 1.00001f;                   // (1e-5 relative slack >> fp32 error)
+            return __builtin_amdgcn_ballot_w64(q.live && !(d2 > lim * lim)) != 0;
+        };
+        const int ngrp = sc.ngrp > 0 ? sc.ngrp : 1;
+        for (int gi = 0; gi < ngrp; gi++) {
+            int k_lo = 0, k_hi = sc.ncl;
+            if (sc.ngrp > 0) {
+                const float gr = gradius[(size_t)l * sc.ngrp + gi];
+                if (gr < 0.0f) continue;
+                if (!in_reach(gcenters[gi], gr)) continue;
+                const int2 gk = granges[gi];
+                k_lo = gk.x, k_hi = gk.y;
+            }
+            for (int k = k_lo; k < k_hi; k++) {
+                if (k == k_first) continue;
+                const int2 range = rg[k];
+                if (range.x >= range.y) continue;
+                if (!in_reach(centers[k], rd[k])) continue;
+                OCC_SCAN1(range.x, range.y)
+            }
+        }
+        OCC_EMIT1(l)
+    }
+}
+#undef OCC_PT1
+#undef OCC_SCAN1
+#undef OCC_EMIT1
+
+// squared extent (bounding-box diagonal of the searched queries, m^2) above which a small launch hands a tile to four waves
+// (0.2 m; splitting EVERY tile of a training batch -- one tile per resident wave -- measured no better: 0.95 against 0.93 ms, the
+// longest one-query job, 64 queries spread over the body, is the floor then)
+constexpr float kSplitExtent2 = 0.04f;
+
+template <bool SPLIT /* small launches: four tickets per tile, spread tiles searched as four one-query jobs */>
 __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     const float *__restrict__ xyz, const float *__restrict__ mask /*nullable*/, int64_t n_rays, int S,
     const float4 *__restrict__ points, const float4 *__restrict__ centers,
@@ -292,7 +423,8 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     const int32_t *__restrict__ qrows /*nullable: ascending list of the samples to query*/,
     const int32_t *__restrict__ ray_start /*with qrows: [n_rays + 1] first list entry of every ray*/,
     const float *__restrict__ center /*nullable: knn_center_kernel's [4] (c, r^2)*/,
-    const int32_t *__restrict__ center_idx /*with center: c's indices [nscale][10]*/) {
+    const int32_t *__restrict__ center_idx /*with center: c's indices [nscale][10]*/,
+    const float split_extent2 /*SPLIT: tiles wider than this (squared) are searched as four one-query jobs*/) {
     const int lane = threadIdx.x & 63;
     float ccx = 0.f, ccy = 0.f, ccz = 0.f, cr2 = 0.f;      // wave-uniform (scalar loads)
     if (center) ccx = center[0], ccy = center[1], ccz = center[2], cr2 = center[3];
@@ -304,7 +436,12 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
     for (;;) {
         unsigned t32 = 0;
         if (lane == 0) t32 = atomicAdd(ticket, 1u);
-        const int64_t tile = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t32);
+        const int64_t job = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t32);
+        // SPLIT: every tile owns four consecutive tickets (tile, part 0 .. 3).  Part 0 searches a compact tile whole; the other
+        // parts re-derive "compact" from the same loads and leave.  A spread tile is searched by all four parts, on four waves at
+        // about the same time, sample slot `part` of its 64 rays each.
+        const int64_t tile = SPLIT ? job >> 2 : job;
+        const int part = SPLIT ? (int)(job & 3) : 0;
         if (tile >= n_tiles) break;
         // lane = one of 64 neighbouring rays (the host orders rays in compact pixel patches),
         // its 4 queries = 4 consecutive samples of that ray
@@ -356,7 +493,7 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
                     live[a] = false;
                     struct __attribute__((packed, aligned(4))) I4 { int v[4]; };
                     struct __attribute__((packed, aligned(4))) I2 { int v[2]; };
-                    for (int l = 0; l < sc.nscale; l++) {
+                    for (int l = 0; part == 0 && l < sc.nscale; l++) {
                         int32_t *out = knn_idxs + (qi[a] * sc.nscale + l) * kK;
                         const int32_t *ci = center_idx + l * kK;
                         *reinterpret_cast<I4 *>(out) = I4{{ci[0], ci[1], ci[2], ci[3]}};
@@ -367,6 +504,44 @@ __global__ __launch_bounds__(256) void msknn_clustered_kernel(
             }
         }
         if (__builtin_amdgcn_ballot_w64(live[0] || live[1] || live[2] || live[3]) == 0) continue;   // whole tile dead (or served by the cache)
+        if constexpr (SPLIT) {
+            // extent of the searched queries: squared diagonal of their bounding box (wave-wide; the same for the tile's four parts)
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int a = 0; a < kQ; a++) {
+                if (live[a]) {
+                    const float v[3] = {qx[a >> 1][a & 1], qy[a >> 1][a & 1], qz[a >> 1][a & 1]};
+#pragma unroll
+                    for (int d = 0; d < 3; d++) lo[d] = fminf(lo[d], v[d]), hi[d] = fmaxf(hi[d], v[d]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+                    hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+                }
+            }
+            const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+            const float ext2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ex * ex + ey * ey + ez * ez)));
+            const bool spread = ext2 > split_extent2;
+            if (!spread && part != 0) continue;
+            if (spread) {              // a lane's query = sample slot `part` of its ray
+                OneQuery q1{0.f, 0.f, 0.f, false};
+                int64_t q1i = 0;
+#pragma unroll
+                for (int a = 0; a < kQ; a++) {
+                    if (a == part) {
+                        q1 = OneQuery{qx[a >> 1][a & 1], qy[a >> 1][a & 1], qz[a >> 1][a & 1], live[a]};
+                        q1i = qi[a];
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(q1.live) != 0)
+                    search_one_query(q1, q1i, lane, points, centers, ranges, radius, gcenters, granges, gradius, sc, knn_idxs);
+                continue;
+            }
+        }
         KBest64 best[kQ];
         float thr[kQ], sb[kQ];
 
@@ -694,7 +869,11 @@ OCC_API int occnerf_msknn_clustered_centered(const float *xyz, const float *mask
     }
     const int64_t tiles = ((n_rays + 63) / 64) * ((samples_per_ray + 3) / 4);
     OCC_REQUIRE(tiles < (1ll << 31), "msknn_clustered: too many tiles for one launch");
-    int64_t blocks = (tiles + 3) / 4;
+    // Small launches (at most 4 tiles per resident wave: a rank's eighth of a frame, a training batch) end with their longest
+    // tile: they run the SPLIT form.  Large ones keep one ticket per tile (four would load every dead or cached tile four times:
+    // +1.5 ms on the benchmark frame, profiles/r06_knn_split_tiles.md).
+    const bool split = tiles <= (int64_t)kNumCU * 12 * 4;
+    int64_t blocks = ((split ? 4 * tiles : tiles) + 3) / 4;      // one wave per ticket, up to the resident limit
     if (blocks > (int64_t)kNumCU * 3) blocks = (int64_t)kNumCU * 3;      // 12 resident waves per CU at this register count
     // Ticket counter of this launch: ONE 64-byte line per (device, stream), zeroed on the launch stream.  Launches on a stream
     // are in order, so the memset of launch n + 1 cannot pass the kernel of launch n, and launches on different streams never
@@ -728,12 +907,13 @@ OCC_API int occnerf_msknn_clustered_centered(const float *xyz, const float *mask
     if (query_rows)
         hipLaunchKernelGGL(ray_list_ranges_kernel, dim3((unsigned)((n_rays + 256) / 256)), dim3(256), 0, as_stream(stream),
                            query_rows, n_query_dev, n_rays, samples_per_ray, ray_start);
-    hipLaunchKernelGGL(msknn_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, mask,
+    auto kern = split ? msknn_clustered_kernel<true> : msknn_clustered_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, mask,
                        n_rays, samples_per_ray, reinterpret_cast<const float4 *>(points),
                        reinterpret_cast<const float4 *>(centers), reinterpret_cast<const int2 *>(cluster_ranges),
                        cluster_radius, reinterpret_cast<const float4 *>(group_centers),
                        reinterpret_cast<const int2 *>(group_ranges), group_radius, sc, knn_idxs, ticket, query_rows, ray_start,
-                       center, center_idx);
+                       center, center_idx, kSplitExtent2);
     return check_launch("msknn_clustered");
 }
 
