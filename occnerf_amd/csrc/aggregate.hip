@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restric
     int prev_id = -2;
     uint32_t prev_w = 0u;
     float acc = 0.0f;
+    const bool pairs = F <= 36 && K <= 64;
     for (int64_t n = n0; n < n1; n++) {
         const int32_t *id = knn + n * K;
         const float *w = atts + n * K;
@@ -37,7 +38,39 @@ __global__ __launch_bounds__(256) void agg_forward_kernel(const float *__restric
             prev_id = my;
             prev_w = myw;
         }
-        if (!same) {
+        if (!same && pairs) {
+            // (round 6) F <= 36, K <= 64: a row is 18 column PAIRS, so three groups of 18 lanes gather three neighbours' rows per
+            // instruction (8 bytes per lane) instead of one row on 35 lanes -- the kernel is bound by the number of gather
+            // instructions (>= 16 cycles each on the texture path).  Group g sums neighbours g, g + 3, ...; the three partial sums
+            // meet through shuffles.  (Another summation order than j = 0 .. K-1: fp32 reassociation, inside the tolerance the
+            // aggregation is held to -- torch's own reduction order is not specified either.)
+            struct __attribute__((packed, aligned(4))) F2 { float v[2]; };
+            const int grp = lane / 18, c2 = lane - grp * 18;
+            const bool two = 2 * c2 + 1 < F, any = grp < 3 && 2 * c2 < F;
+            const int my_id = lane < K ? id[lane] : 0;
+            const float my_w = lane < K ? w[lane] : 0.0f;
+            float s0 = 0.0f, s1 = 0.0f;
+            for (int j = 0; j < K; j += 3) {
+                const int jj = j + grp < K ? j + grp : K - 1;
+                const int p = __shfl(my_id, jj);
+                const float wv = __shfl(my_w, jj);                       // (every lane takes part: a masked-off source lane reads as 0)
+                const float wj = (grp < 3 && j + grp < K) ? wv : 0.0f;
+                if (any) {
+                    const char *row = reinterpret_cast<const char *>(feats) + ((uint32_t)p * (uint32_t)F + 2u * (uint32_t)c2) * 4u;
+                    if (two) {
+                        const F2 v = *reinterpret_cast<const F2 *>(row);
+                        s0 = __fadd_rn(s0, __fmul_rn(wj, v.v[0]));
+                        s1 = __fadd_rn(s1, __fmul_rn(wj, v.v[1]));
+                    } else {
+                        s0 = __fadd_rn(s0, __fmul_rn(wj, *reinterpret_cast<const float *>(row)));
+                    }
+                }
+            }
+            const int src = lane >> 1;                                   // lane c takes column c: pair c / 2, element c & 1
+            const float t0 = __fadd_rn(__fadd_rn(__shfl(s0, src), __shfl(s0, src + 18)), __shfl(s0, src + 36));
+            const float t1 = __fadd_rn(__fadd_rn(__shfl(s1, src), __shfl(s1, src + 18)), __shfl(s1, src + 36));
+            acc = (lane & 1) ? t1 : t0;
+        } else if (!same) {
             acc = 0.0f;
             for (int j0 = 0; j0 < K; j0 += 64) {                       // ids / weights of up to 64 neighbours at once
                 const int jj = j0 + lane;
