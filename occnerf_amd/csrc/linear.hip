@@ -342,7 +342,9 @@ struct WgradArgs {
 template <bool BF16>
 __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
     constexpr int ESZ = BF16 ? 2 : 4;
-    constexpr int TP = 256 * ESZ + 16;                 // tile row pitch, bytes
+    // tile row pitch, bytes: bf16 rows 32 B apart modulo the 256-byte bank row, so that the four rows a 16-lane group of
+    // ds_read_b64_tr_b16 touches fall into disjoint banks
+    constexpr int TP = BF16 ? 256 * ESZ + 32 : 256 * ESZ + 16;
     constexpr int kTile = 32 * TP;
     constexpr int PIECES = BF16 ? 2 : 4;               // 16-byte pieces per thread per 32 x 256 tile
     __shared__ __attribute__((aligned(16))) char tiles[2 * 2 * kTile];      // [buffer][dz | x]
@@ -364,6 +366,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; r++) acc[u][v][r] = 0.0f;
     float dbs[2] = {0.0f, 0.0f};
 
+    // (one tile in flight in registers beside the one being multiplied; a second register set, two tiles in flight, measured
+    // no gain in round 6: the loop was paced by its LDS operand reads, not by the HBM round trip)
     u32x4 rz[PIECES], rx[PIECES];
     auto fetch = [&](int t) {
         const int64_t r0 = m_begin + (int64_t)t * 32;
@@ -416,36 +420,53 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
         const char *tz = tiles + (t & 1) * 2 * kTile, *tx = tz + kTile;
         if (nact[0] && kact[0]) {
             if constexpr (BF16) {
+                // Operand fragments by the LDS TRANSPOSE READ of gfx950 (round 6).  The contraction runs over the tile's ROWS, so a
+                // lane's 8 operand values are 8 consecutive rows of ONE column of the row-major tile: eight 2-byte reads + packing
+                // per operand before (96 LDS instructions per wave per tile: the loop was paced by them, 178 us per layer), two
+                // ds_read_b64_tr_b16 now.  Measured semantics (tools/tr_b16_probe.hip): in a group of 16 lanes, lane p supplies
+                // the address of 4 contiguous elements = row p >> 2, column chunk p & 3 of a 4 x 16 block; lane l receives column
+                // l & 15 of the block's four rows.  Lane (i, h) of the MFMA operand = group g = lane >> 4: columns 16 (g & 1) ..,
+                // rows 8 (g >> 1) + {0..3} in the first read, + {4..7} in the second.  Same fragments as before, bit for bit.
+                const int g4 = lane >> 4, p16 = lane & 15;
+                const unsigned lane_off = (unsigned)((8 * (g4 >> 1) + (p16 >> 2)) * TP + (16 * (g4 & 1) + 4 * (p16 & 3)) * 2);
+                const unsigned tz_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)tz + lane_off;
+                const unsigned tx_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)tx + lane_off;
+                auto tr = [](unsigned addr) -> u32x2 {
+                    u32x2 v;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+                    return v;
+                };
 #pragma unroll
                 for (int s = 0; s < 2; s++) {                      // k-steps of 16 rows
-                    const int rbase = s * 16 + 8 * h;
+                    u32x2 ra[2][2], rb[4][2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+#pragma unroll
+                        for (int q = 0; q < 2; q++) ra[u][q] = tr(tz_lds + (unsigned)((s * 16 + 4 * q) * TP + (2 * wn + u) * 64));
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+#pragma unroll
+                        for (int q = 0; q < 2; q++) rb[v][q] = tr(tx_lds + (unsigned)((s * 16 + 4 * q) * TP + (4 * wk + v) * 64));
+                    }
+                    // (the reads are asynchronous and invisible to the compiler: the wait takes every result as an operand, so no
+                    // use can be scheduled above it)
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(rb[0][0]), "+v"(rb[0][1]),
+                                   "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1])
+                                 :
+                                 : "memory");
                     u32x4 fa[2], fb[4];
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
-                        if (!nact[u]) continue;
-                        const char *col = tz + ((2 * wn + u) * 32 + i) * 2;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t lo = *reinterpret_cast<const uint16_t *>(col + (rbase + 2 * j) * TP);
-                            const uint32_t hi = *reinterpret_cast<const uint16_t *>(col + (rbase + 2 * j + 1) * TP);
-                            fa[u][j] = lo | (hi << 16);
-                        }
-                        if (wk == 0) {
+                        fa[u] = u32x4{ra[u][0][0], ra[u][0][1], ra[u][1][0], ra[u][1][1]};
+                        if (nact[u] && wk == 0) {
 #pragma unroll
                             for (int j = 0; j < 4; j++) dbs[u] += bf16_lo(fa[u][j]) + bf16_hi(fa[u][j]);
                         }
                     }
 #pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        if (!kact[v]) continue;
-                        const char *col = tx + ((4 * wk + v) * 32 + i) * 2;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t lo = *reinterpret_cast<const uint16_t *>(col + (rbase + 2 * j) * TP);
-                            const uint32_t hi = *reinterpret_cast<const uint16_t *>(col + (rbase + 2 * j + 1) * TP);
-                            fb[v][j] = lo | (hi << 16);
-                        }
-                    }
+                    for (int v = 0; v < 4; v++) fb[v] = u32x4{rb[v][0][0], rb[v][0][1], rb[v][1][0], rb[v][1][1]};
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         if (!nact[u]) continue;
