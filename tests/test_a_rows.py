@@ -452,6 +452,52 @@ def test_msknn_cluster_groups_change_nothing(ops):
         same(o, outs[0], 'cluster groups')
 
 
+def test_msknn_small_and_large_launch_forms_agree(ops):
+    """Round 6: launches of at most 4 tiles per resident wave run `msknn_clustered_kernel<SPLIT>` (four tickets per tile, tiles wider
+    than 0.2 m searched as four one-query jobs), larger ones the one-ticket form.  The SAME queries through both -- one launch of
+    12 800 tiles, and the same rays in two launches of 6 400 -- must give the same indices, mask, query-list and centre-cache
+    modes included; a sample of them is checked against the brute-force kernel as well."""
+    ctx = util.model_context(0, False)
+    m = _dev_model(ctx, ops)
+    cl = _clusters(ctx)
+    rng = np.random.RandomState(17)
+    n_rays, S = 64 * 400, 128                                   # 400 ray blocks x 32 chunks = 12 800 tiles > 12 288
+    # rays of 128 samples marching through the body: neighbouring samples close, neighbouring rays anywhere (spread tiles)
+    start = ctx['point_base'][rng.randint(0, 6890, n_rays)] + rng.randn(n_rays, 3).astype(np.float32) * 0.05
+    step = rng.randn(n_rays, 3).astype(np.float32)
+    step *= (0.004 / np.linalg.norm(step, axis=1, keepdims=True)).astype(np.float32)
+    q = (start[:, None, :] + step[:, None, :] * np.arange(S, dtype=np.float32)[None, :, None]).reshape(-1, 3).astype(np.float32)
+    qd = T(q)
+    half = n_rays // 2
+    keep = T((rng.rand(n_rays * S) < 0.5).astype(np.float32))
+    rows_all, count_all = ops.live_rows(keep)
+    c = np.array([-4.1e-5, -1.5e-5, -5.7e-6], np.float32)
+    center = ops.knn_center(T(c), m['points'], m['imap'], m['begin'])
+
+    def two_launches(**kw):
+        outs = []
+        for lo, hi in ((0, half), (half, n_rays)):
+            sub = {}
+            if 'mask' in kw:
+                sub['mask'] = kw['mask'][lo * S:hi * S].contiguous()
+            if 'rows' in kw:
+                r, cnt = ops.live_rows(keep[lo * S:hi * S].contiguous())
+                sub['rows'], sub['count'] = r, cnt
+            if 'center' in kw:
+                sub['center'] = kw['center']
+            outs.append(ops.msknn_clustered(qd[lo * S:hi * S].contiguous(), hi - lo, S, cl, [1, 1, 1, 0], **sub))
+        return torch.cat(outs)
+    live = keep.cpu().numpy() > 0
+    for kw in ({}, {'mask': keep}, {'rows': rows_all, 'count': count_all}, {'center': center}):
+        whole = ops.msknn_clustered(qd, n_rays, S, cl, [1, 1, 1, 0], **kw)
+        parts = two_launches(**kw)
+        sel = live if ('mask' in kw or 'rows' in kw) else np.ones(n_rays * S, bool)
+        same(parts.cpu().numpy()[sel], whole.cpu().numpy()[sel], f'split form vs one-ticket form ({sorted(kw)})')
+    pick = rng.choice(n_rays * S, 20000, replace=False)
+    brute = ops.msknn(T(q[pick]), m['points'], m['imap'], m['begin'], m['seed'])
+    same(whole.cpu().numpy()[pick], brute.cpu().numpy(), 'clustered (centre cache) vs brute force')
+
+
 def test_point_stage_bit_exact(case, ops, oracle):
     g, ctx, o = case
     m = _dev_model(ctx, ops)
