@@ -200,7 +200,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nonrigid_lds_kernel(const floa
                             : oct == 3 ? prm.hann[3] : oct == 4 ? prm.hann[4] : prm.hann[5];
             const float a = __fmul_rn(pc, (float)(1 << oct));
             float sa, ca;
+#ifdef OCC_NR16_EXP_NO_SINCOS      // (tools/nr16_phases.py: what the ten sincosf per wave pass cost -- wrong offsets, a timing build only)
+            sa = a, ca = 1.0f - a;
+#else
             sincosf(a, &sa, &ca);                 // one argument reduction for both
+#endif
             const float sv = __fmul_rn(wgt, sa), cv = __fmul_rn(wgt, ca);
             if (m < 4) {
                 e[T][2 * m] = sv;
