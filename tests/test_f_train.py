@@ -85,7 +85,10 @@ def test_linear_mask_epilogue(bf16):
 
 @pytest.mark.parametrize('bf16', [False, True])
 @pytest.mark.parametrize('M,N,K', [(5000, 256, 256), (333, 96, 256), (70000, 256, 96), (1, 32, 256), (31, 32, 32),
-                                   (33, 192, 128)])
+                                   (33, 192, 128),
+                                   # >= 4 tiles of 32 rows per workgroup at 256 x 256: the two-tiles-in-flight form (bf16), with a
+                                   # partial last tile, an odd and an even count of whole tiles
+                                   (40017, 256, 256), (262144 + 33, 256, 256), (256 * 32 * 5, 256, 256)])
 def test_linear_wgrad(bf16, M, N, K):
     """dW = dz^T x and db = column sums of dz through the row/column maps (a permutation with holes), ragged M."""
     from occnerf_amd import train_ops as to
